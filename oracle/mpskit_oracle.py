@@ -1,0 +1,1180 @@
+"""CPU ORACLE -- test infrastructure only, NOT the product.
+
+NumPy (fp64 / complex128) restatement of the hot path of stecrotti/MPSKit.jl v0.10.2
+(reference mounted at /root/reference, Julia, never executed: no Julia toolchain in this
+image).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; the product path (``mpskit.jl_amd``) never does.
+
+Parity status: the reference's tests hold NO golden vectors for the hot-path contractions
+ -> element-level parity is "parity unpinned" with respect to TensorKit's
+own output; the oracle is pinned instead by
+  (1) the ED identity of src/algorithms/ED.jl:4-53 (dAC on an untruncated chain == dense H v),
+  (2) dense exact diagonalisation / free-fermion energies,
+  (3) the energies recorded in the reference's rendered docs
+      (docs/src/examples/quantum1d/3.ising-dqpt/index.md:48,118 ; 1.ising-cft/index.md:362),
+  (4) the property tests of test/operators.jl:207-225 and test/states.jl:25-28.
+See tests/test_oracle_*.py.
+
+Index conventions (TensorKit order):
+  MPS tensor  x[a, s, b]      (V_l (x) P <- V_r)               shape (Dl, d, Dr)
+  left env    GL[i][p, w, a]  (V_l (x) W_i' <- V_l)            shape (Dl, chi_i, Dl)
+  right env   GR[j][b, v, q]                                    shape (Dr, chi_j, Dr)
+  MPO block   O[w, t, s, v]   (W_l (x) P <- P (x) W_r), t = out physical, s = in physical
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Operators: block-sparse MPO slices  (src/operators/sparsempo/sparseslice.jl:13-106,
+#                                       src/operators/mpohamiltonian.jl:8-31)
+# --------------------------------------------------------------------------------------
+
+
+class SparseMPOSlice:
+    """odim x odim matrix of blocks; a block is 0, a scalar c (== c * 1_d (x) 1_chi) or a dense
+    array [chi_i, d, d, chi_j]  (sparseslice.jl:13-27, 74-106)."""
+
+    def __init__(self, odim, d, chil, chir, blocks):
+        self.odim, self.d = int(odim), int(d)
+        self.chil, self.chir = list(chil), list(chir)
+        self.Os = {}
+        for (i, j), v in blocks.items():
+            self[i, j] = v
+
+    # sparseslice.jl:40-72 : scalar / zero detection on assignment
+    def __setitem__(self, ij, v):
+        i, j = ij
+        if np.isscalar(v):
+            if v != 0:
+                self.Os[(i, j)] = v
+            else:
+                self.Os.pop((i, j), None)
+            return
+        v = np.asarray(v)
+        if v.ndim == 2:  # plain d x d operator -> chi = 1 block
+            v = v[None, :, :, None]
+        assert v.shape == (self.chil[i], self.d, self.d, self.chir[j]), (v.shape, i, j)
+        if self.chil[i] == self.chir[j]:
+            c = v[0, 0, 0, 0]
+            ident = np.einsum("wv,ts->wtsv", np.eye(self.chil[i]), np.eye(self.d))
+            if np.allclose(v, c * ident, rtol=0, atol=1e-14 * max(1.0, abs(c))) and c != 0:
+                self.Os[(i, j)] = 1.0 if abs(c - 1) < 1e-14 else c
+                return
+        if np.allclose(v, 0, atol=1e-14, rtol=0):
+            self.Os.pop((i, j), None)
+        else:
+            self.Os[(i, j)] = v
+
+    def keys(self):  # sparseslice.jl:74-76
+        return sorted(self.Os.keys(), key=lambda t: (t[1], t[0]))  # column-major like product()
+
+    def contains(self, i, j):  # :101-103
+        return (i, j) in self.Os
+
+    def isscal(self, i, j):  # :104-106
+        return (i, j) in self.Os and np.isscalar(self.Os[(i, j)])
+
+    def keys_col(self, k):
+        return [i for i in range(self.odim) if (i, k) in self.Os]
+
+    def keys_row(self, j):
+        return [k for k in range(self.odim) if (j, k) in self.Os]
+
+    def dense(self, i, j):
+        """block as a [chi_i, d, d, chi_j] array (sparseslice.jl:44-56: scalar -> c * tau-identity)."""
+        v = self.Os.get((i, j), 0.0)
+        if np.isscalar(v):
+            assert self.chil[i] == self.chir[j] or v == 0
+            if v == 0:
+                return np.zeros((self.chil[i], self.d, self.d, self.chir[j]))
+            return v * np.einsum("wv,ts->wtsv", np.eye(self.chil[i]), np.eye(self.d))
+        return v
+
+    def full(self):
+        """whole slice as one dense [W_l, d, d, W_r] array (W = sum chi)."""
+        Wl, Wr = sum(self.chil), sum(self.chir)
+        offl = np.concatenate([[0], np.cumsum(self.chil)])
+        offr = np.concatenate([[0], np.cumsum(self.chir)])
+        dt = np.result_type(*[np.asarray(v).dtype for v in self.Os.values()], np.float64)
+        out = np.zeros((Wl, self.d, self.d, Wr), dtype=dt)
+        for (i, j) in self.Os:
+            out[offl[i]:offl[i + 1], :, :, offr[j]:offr[j + 1]] = self.dense(i, j)
+        return out
+
+    @property
+    def dtype(self):
+        return np.result_type(*[np.asarray(v).dtype for v in self.Os.values()], np.float64)
+
+
+class MPOHamiltonian:
+    """Periodic list of slices with H[.][0,0] = 1 and H[.][odim-1,odim-1] = 1
+    (mpohamiltonian.jl:8-31)."""
+
+    def __init__(self, slices):
+        self.slices = list(slices)
+        self.odim = self.slices[0].odim
+        self.period = len(self.slices)
+
+    def __getitem__(self, i):
+        return self.slices[i % self.period]
+
+    def __len__(self):
+        return self.period
+
+    def isid(self, i):  # mpohamiltonian.jl:53-58 (0-based level i)
+        return all(s.isscal(i, i) and abs(s.Os[(i, i)] - 1) < 1e-14 for s in self.slices)
+
+    @property
+    def d(self):
+        return self.slices[0].d
+
+
+def mpoham_from_chain(ops_rows, d):
+    """Build a chi=1 MPOHamiltonian slice from {(i,j): scalar | d x d matrix}
+    (docs/src/man/operators.md:52-78 style 'data[1, i, j] = ...')."""
+    odim = 1 + max(max(i, j) for (i, j) in ops_rows)
+    return SparseMPOSlice(odim, d, [1] * odim, [1] * odim, ops_rows)
+
+
+def mpoham_from_twosite(h2, tol=1e-12):
+    """MPOHamiltonian(h::TensorMap two-site)  (mpohamiltonian.jl:16-31, utility.jl:42-54).
+
+    h2[t1, t2, s1, s2] (out1, out2 <- in1, in2).  SVD split h = A.B with A absorbing U*S and
+    truncation truncbelow(tol), then the 3x3 block matrix [[1, A, 0], [0, 0, B], [0, 0, 1]]."""
+    d = h2.shape[0]
+    # matrix with rows (t1, s1) and columns (t2, s2)
+    M = np.transpose(h2, (0, 2, 1, 3)).reshape(d * d, d * d)
+    U, S, Vh = np.linalg.svd(M)
+    keep = S > tol
+    U, S, Vh = U[:, keep], S[keep], Vh[keep, :]
+    r = len(S)
+    A = (U * S).reshape(d, d, r)  # [t1, s1, r]
+    B = Vh.reshape(r, d, d)  # [r, t2, s2]
+    Ablk = np.transpose(A, (0, 1, 2))[None, :, :, :]  # [1, t, s, r]
+    Bblk = B[:, :, :, None]  # [r, t, s, 1]
+    return MPOHamiltonian([SparseMPOSlice(3, d, [1, r, 1], [1, r, 1],
+                                          {(0, 0): 1.0, (0, 1): Ablk, (1, 2): Bblk, (2, 2): 1.0})])
+
+
+# ---- spin / fermion operator tables --------------------------------------------------
+
+def spin_ops(spin=0.5):
+    d = int(round(2 * spin + 1))
+    m = spin - np.arange(d)
+    Sz = np.diag(m)
+    Sp = np.zeros((d, d))
+    for k in range(1, d):
+        Sp[k - 1, k] = math.sqrt(spin * (spin + 1) - m[k] * (m[k] + 1))
+    return Sz, Sp, Sp.T.copy()
+
+
+def heisenberg_mpo(spin=0.5, J=1.0):
+    """Real 5x5 Heisenberg MPO, H = J sum Sz Sz + (S+ S- + S- S+)/2  (block structure of
+    docs/src/man/operators.md:67-78, rewritten in the real S+/S- basis; W = 5, all chi = 1)."""
+    Sz, Sp, Sm = spin_ops(spin)
+    d = Sz.shape[0]
+    return MPOHamiltonian([mpoham_from_chain({(0, 0): 1.0, (4, 4): 1.0,
+                                              (0, 1): J * Sz, (1, 4): Sz,
+                                              (0, 2): 0.5 * J * Sp, (2, 4): Sm,
+                                              (0, 3): 0.5 * J * Sm, (3, 4): Sp}, d)])
+
+
+def heisenberg_pauli_mpo():
+    """Complex XXX MPO exactly as docs/src/man/operators.md:67-78 (Pauli X, Y, Z)."""
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    Y = np.array([[0, -1j], [1j, 0]])
+    Z = np.array([[1, 0], [0, -1]], dtype=complex)
+    return MPOHamiltonian([mpoham_from_chain({(0, 0): 1.0, (4, 4): 1.0, (0, 1): X, (1, 4): X,
+                                              (0, 2): Y, (2, 4): Y, (0, 3): Z, (3, 4): Z}, 2)])
+
+
+def tfi_mpo(J=1.0, g=1.0):
+    """H = -J sum Z Z - g sum X (Pauli), 3x3 MPO of docs/src/man/operators.md:52-58."""
+    X = np.array([[0.0, 1], [1, 0]])
+    Z = np.array([[1.0, 0], [0, -1]])
+    return MPOHamiltonian([mpoham_from_chain({(0, 0): 1.0, (2, 2): 1.0, (0, 1): -J * Z, (1, 2): Z,
+                                              (0, 2): -g * X}, 2)])
+
+
+def tfi_twosite_mpo(g=1.0):
+    """test/setup.jl:38-44 : MPOHamiltonian(-(ZZ + g/2 (X1 + 1X)))  (edge sites get half field)."""
+    X = np.array([[0.0, 1], [1, 0]])
+    Z = np.array([[1.0, 0], [0, -1]])
+    E = np.eye(2)
+    H = np.kron(Z, Z) + (g / 2) * (np.kron(X, E) + np.kron(E, X))
+    return mpoham_from_twosite(-H.reshape(2, 2, 2, 2))
+
+
+def hubbard_mpo(t=1.0, U=4.0):
+    """Spinful Hubbard chain via Jordan-Wigner, d = 4 (|0>, |up>, |dn>, |updn>), W = 6.
+    Not in the reference repo (lives in MPSKitModels); same block form as mpohamiltonian.jl:19-31."""
+    # single-mode operators
+    c = np.array([[0.0, 1], [0, 0]])
+    n = c.T @ c
+    P = np.diag([1.0, -1.0])
+    I2 = np.eye(2)
+    cu = np.kron(c, I2)          # up annihilator
+    cd = np.kron(P, c)           # down annihilator with on-site string
+    F = np.kron(P, P)            # fermion parity of the site
+    nu, nd = cu.T @ cu, cd.T @ cd
+    blocks = {(0, 0): 1.0, (5, 5): 1.0, (0, 5): U * (nu @ nd)}
+    # -t (c^dag_i c_{i+1} + h.c.) per spin; string F attached to the left operator
+    blocks[(0, 1)] = -t * (cu.T @ F); blocks[(1, 5)] = cu
+    blocks[(0, 2)] = t * (cu @ F);    blocks[(2, 5)] = cu.T
+    blocks[(0, 3)] = -t * (cd.T @ F); blocks[(3, 5)] = cd
+    blocks[(0, 4)] = t * (cd @ F);    blocks[(4, 5)] = cd.T
+    return MPOHamiltonian([mpoham_from_chain(blocks, 4)])
+
+
+def dense_hamiltonian(H: MPOHamiltonian, L):
+    """Dense 2^L-like matrix of the finite-chain Hamiltonian encoded by the MPO with the FinEnv
+    boundary vectors (FinEnv.jl:41-70: left picks level 0, right picks level odim-1)."""
+    d = H.d
+    cur = None  # list over right MPO index of dense operators
+    for i in range(L):
+        Of = H[i].full()  # [Wl, t, s, Wr]
+        if cur is None:
+            cur = [Of[0, :, :, v] for v in range(Of.shape[3])]
+        else:
+            dim = cur[0].shape[0]
+            new = []
+            for v in range(Of.shape[3]):
+                acc = np.zeros((dim * d, dim * d), dtype=np.result_type(Of.dtype, cur[0].dtype))
+                for w in range(Of.shape[0]):
+                    if np.any(Of[w, :, :, v] != 0) and np.any(cur[w] != 0):
+                        acc += np.kron(cur[w], Of[w, :, :, v])
+                new.append(acc)
+            cur = new
+    return cur[-1]
+
+
+# --------------------------------------------------------------------------------------
+# Hot-path contractions (src/algorithms/derivatives.jl, src/transfermatrix/transfer.jl)
+# --------------------------------------------------------------------------------------
+
+def dAC_block(x, O, GLi, GRj):
+    """derivatives.jl:95-104.  O dense [chi,d,d,chi] or scalar."""
+    if np.isscalar(O):
+        return O * np.einsum("pwa,asb,bwq->psq", GLi, x, GRj, optimize=True)
+    return np.einsum("pwa,asb,wtsv,bvq->ptq", GLi, x, O, GRj, optimize=True)
+
+
+def dAC(x, H: SparseMPOSlice, GL, GR):
+    """derivatives.jl:77-93: sum over non-zero blocks, one contraction per block."""
+    y = None
+    for (i, j) in H.keys():
+        t = dAC_block(x, H.Os[(i, j)], GL[i], GR[j])
+        y = t if y is None else y + t
+    return y
+
+
+def dC(x, GL, GR):
+    """derivatives.jl:171-189."""
+    y = None
+    for le, re in zip(GL, GR):
+        t = np.einsum("pwa,ab,bwq->pq", le, x, re, optimize=True)
+        y = t if y is None else y + t
+    return y
+
+
+def dAC2(x, h1: SparseMPOSlice, h2: SparseMPOSlice, GL, GR):
+    """derivatives.jl:119-154; x[a, s1, b, s2] (V_l (x) P <- V_r (x) P)."""
+    hl = [None] * h1.odim
+    for j in range(h1.odim):
+        cur = None
+        for i in h1.keys_col(j):
+            t = np.einsum("pwa,wtsu,asbr->ptbru", GL[i], h1.dense(i, j), x, optimize=True)
+            cur = t if cur is None else cur + t
+        hl[j] = cur
+    out = None
+    for (j, k) in h2.keys():
+        if hl[j] is None:
+            continue
+        t = np.einsum("ptbru,uzrv,bvq->ptqz", hl[j], h2.dense(j, k), GR[k], optimize=True)
+        out = t if out is None else out + t
+    return out
+
+
+def transfer_left_block(v, O, A, Ab):
+    """transfer.jl:105-107 (dense) / :66-70 (pass-through leg)."""
+    if O is None:
+        return np.einsum("pwa,asb,psq->qwb", v, A, np.conj(Ab), optimize=True)
+    return np.einsum("pwa,asb,wtsv,ptq->qvb", v, A, O, np.conj(Ab), optimize=True)
+
+
+def transfer_right_block(v, O, A, Ab):
+    """transfer.jl:108-110 / :71-75."""
+    if O is None:
+        return np.einsum("asb,psq,bwq->awp", A, np.conj(Ab), v, optimize=True)
+    return np.einsum("asb,wtsv,ptq,bvq->awp", A, O, np.conj(Ab), v, optimize=True)
+
+
+def transfer_left(vec, ham: SparseMPOSlice, A, Ab):
+    """transfer.jl:166-211 (sequential branch)."""
+    out = []
+    for k in range(ham.odim):
+        els = ham.keys_col(k)
+        if not els:
+            out.append(np.zeros((Ab.shape[2], ham.chir[k], A.shape[2]),
+                                dtype=np.result_type(vec[0], A)))
+            continue
+        acc = None
+        for j in els:
+            if ham.isscal(j, k):
+                t = ham.Os[(j, k)] * transfer_left_block(vec[j], None, A, Ab)
+            else:
+                t = transfer_left_block(vec[j], ham.Os[(j, k)], A, Ab)
+            acc = t if acc is None else acc + t
+        out.append(acc)
+    return out
+
+
+def transfer_right(vec, ham: SparseMPOSlice, A, Ab):
+    """transfer.jl:212-259."""
+    out = []
+    for j in range(ham.odim):
+        els = ham.keys_row(j)
+        if not els:
+            out.append(np.zeros((A.shape[0], ham.chil[j], Ab.shape[0]),
+                                dtype=np.result_type(vec[0], A)))
+            continue
+        acc = None
+        for k in els:
+            if ham.isscal(j, k):
+                t = ham.Os[(j, k)] * transfer_right_block(vec[k], None, A, Ab)
+            else:
+                t = transfer_right_block(vec[k], ham.Os[(j, k)], A, Ab)
+            acc = t if acc is None else acc + t
+        out.append(acc)
+    return out
+
+
+def transfer_left_bond(v, A, Ab):
+    """transfer.jl:18-25 : v'[q,b] = v[p,a] A[a,s,b] conj(Ab[p,s,q])."""
+    return np.einsum("pa,asb,psq->qb", v, A, np.conj(Ab), optimize=True)
+
+
+def transfer_right_bond(v, A, Ab):
+    """transfer.jl:38-45 : v'[a,p] = A[a,s,b] conj(Ab[p,s,q]) v[b,q]."""
+    return np.einsum("asb,psq,bq->ap", A, np.conj(Ab), v, optimize=True)
+
+
+def regularize_env(v, lvec, rvec):
+    """transfermatrix.jl:74-76 : v[:,w,:] -= <lvec, v[:,w,:]> rvec."""
+    coef = np.einsum("xy,ywx->w", lvec, v)
+    return v - np.einsum("w,pq->pwq", coef, rvec)
+
+
+# --------------------------------------------------------------------------------------
+# Gauge steps (TensorKit leftorth QRpos / rightorth LQpos / tsvd; call sites orthoview.jl:52,56)
+# --------------------------------------------------------------------------------------
+
+def qrpos(M):
+    Q, R = np.linalg.qr(M)  # reduced
+    dg = np.diagonal(R).copy()
+    ph = np.where(np.abs(dg) > 0, dg / np.where(np.abs(dg) > 0, np.abs(dg), 1), 1.0)
+    return Q * ph[None, :], np.conj(ph)[:, None] * R
+
+
+def lqpos(M):
+    Q, R = qrpos(M.conj().T)
+    return R.conj().T, Q.conj().T
+
+
+def leftorth(A):
+    """A[a,s,b] -> AL[a,s,k], C[k,b] with diag(C) > 0."""
+    Dl, d, Dr = A.shape
+    Q, R = qrpos(A.reshape(Dl * d, Dr))
+    return Q.reshape(Dl, d, Q.shape[1]), R
+
+
+def rightorth(A):
+    """A[a,s,b] -> C[a,k], AR[k,s,b] with diag(C) > 0 (utility.jl:6-10 tail transpose)."""
+    Dl, d, Dr = A.shape
+    L, Q = lqpos(A.reshape(Dl, d * Dr))
+    return L, Q.reshape(Q.shape[0], d, Dr)
+
+
+def tsvd(theta, truncdim=None, truncerr=None):
+    """theta[a,s1,b,s2] -> U[a,s1,k], S[k], Vh[k,b,s2] (dmrg.jl:96).  truncerr: relative 2-norm
+    of discarded weight (TensorKit truncerr semantics, p = 2)."""
+    Dl, d1, Dr, d2 = theta.shape
+    M = np.transpose(theta, (0, 1, 3, 2)).reshape(Dl * d1, d2 * Dr)  # cols (s2, b)
+    U, S, Vh = np.linalg.svd(M, full_matrices=False)
+    k = len(S)
+    if truncdim is not None:
+        k = min(k, truncdim)
+    if truncerr is not None:
+        tot = np.linalg.norm(S)
+        while k > 1 and np.linalg.norm(S[k - 1:]) <= truncerr * tot:
+            k -= 1
+    err = np.linalg.norm(S[k:])
+    U, S, Vh = U[:, :k], S[:k], Vh[:k]
+    Vh = np.transpose(Vh.reshape(k, d2, Dr), (0, 2, 1))  # [k, b, s2]
+    return U.reshape(Dl, d1, k), S, Vh, err
+
+
+# --------------------------------------------------------------------------------------
+# Krylov (KrylovKit eigsolve/schursolve stand-in; fixedpoint.jl:9-30)
+# --------------------------------------------------------------------------------------
+
+def eigsolve_sr(matvec, x0, tol=1e-12, krylovdim=30, maxiter=100, fixed_matvecs=None):
+    """Smallest-real eigenpair of a Hermitian operator by restarted Lanczos/Arnoldi with full
+    (twice-iterated) Gram-Schmidt, 'eager' convergence test every step
+    (defaults.jl:33 Arnoldi(; tol, maxiter, eager=true); orth = ModifiedGramSchmidt2).
+    fixed_matvecs: do exactly this many matvecs (bench mode)."""
+    shape = x0.shape
+    v = x0.reshape(-1).astype(np.result_type(x0.dtype, np.float64))
+    nmv = 0
+    lam = 0.0
+    for _restart in range(maxiter):
+        V = [v / np.linalg.norm(v)]
+        Hm = np.zeros((krylovdim + 1, krylovdim), dtype=v.dtype)
+        k = 0
+        conv = False
+        while k < krylovdim:
+            w = matvec(V[k].reshape(shape)).reshape(-1)
+            nmv += 1
+            for _ in range(2):
+                for i in range(k + 1):
+                    c = np.vdot(V[i], w)
+                    Hm[i, k] += c
+                    w = w - c * V[i]
+            beta = np.linalg.norm(w)
+            Hm[k + 1, k] = beta
+            k += 1
+            Hk = Hm[:k, :k]
+            ev, S = np.linalg.eigh((Hk + Hk.conj().T) / 2)
+            lam, s = ev[0], S[:, 0]
+            res = abs(beta * s[-1])
+            done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
+            if (fixed_matvecs is None and res < tol) or beta < 1e-300 or done_fixed:
+                conv = True
+                break
+            V.append(w / beta)
+        v = sum(s[i] * V[i] for i in range(k))
+        if conv:
+            break
+    v = v / np.linalg.norm(v)
+    return lam, v.reshape(shape), nmv
+
+
+def eigsolve_lm(matvec, x0, tol=1e-12, krylovdim=30, maxiter=100):
+    """Largest-magnitude eigenpair of a general operator by restarted Arnoldi (ortho.jl:184,241)."""
+    shape = x0.shape
+    v = x0.reshape(-1).astype(complex)
+    lam = 0.0
+    for _restart in range(maxiter):
+        V = [v / np.linalg.norm(v)]
+        Hm = np.zeros((krylovdim + 1, krylovdim), dtype=complex)
+        k = 0
+        conv = False
+        while k < krylovdim:
+            w = matvec(V[k].reshape(shape)).reshape(-1)
+            for _ in range(2):
+                for i in range(k + 1):
+                    c = np.vdot(V[i], w)
+                    Hm[i, k] += c
+                    w = w - c * V[i]
+            beta = np.linalg.norm(w)
+            Hm[k + 1, k] = beta
+            k += 1
+            ev, S = np.linalg.eig(Hm[:k, :k])
+            idx = np.argmax(np.abs(ev))
+            lam, s = ev[idx], S[:, idx]
+            res = abs(beta * s[-1])
+            if res < tol or beta < 1e-300:
+                conv = True
+                break
+            V.append(w / beta)
+        v = sum(s[i] * V[i] for i in range(k))
+        if conv:
+            break
+    v = v / np.linalg.norm(v)
+    return lam, v.reshape(shape)
+
+
+def gmres(matvec, b, x0, tol=1e-12, krylovdim=30, maxiter=100):
+    """Restarted GMRES solving matvec(x) = b  (KrylovKit.linsolve stand-in, mpohaminfenv.jl:95)."""
+    shape = b.shape
+    bb = b.reshape(-1)
+    x = x0.reshape(-1).astype(np.result_type(b.dtype, x0.dtype, np.float64))
+    bnorm = np.linalg.norm(bb)
+    if bnorm == 0:
+        return np.zeros(shape, dtype=x.dtype)
+    for _ in range(maxiter):
+        r = bb - matvec(x.reshape(shape)).reshape(-1)
+        beta = np.linalg.norm(r)
+        if beta <= tol:
+            break
+        V = [r / beta]
+        Hm = np.zeros((krylovdim + 1, krylovdim), dtype=x.dtype)
+        k = 0
+        y = None
+        while k < krylovdim:
+            w = matvec(V[k].reshape(shape)).reshape(-1)
+            for _ in range(2):
+                for i in range(k + 1):
+                    c = np.vdot(V[i], w)
+                    Hm[i, k] += c
+                    w = w - c * V[i]
+            hn = np.linalg.norm(w)
+            Hm[k + 1, k] = hn
+            k += 1
+            e1 = np.zeros(k + 1, dtype=x.dtype)
+            e1[0] = beta
+            y, *_ = np.linalg.lstsq(Hm[:k + 1, :k], e1, rcond=None)
+            res = np.linalg.norm(Hm[:k + 1, :k] @ y - e1)
+            if res <= tol or hn < 1e-300:
+                break
+            V.append(w / hn)
+        x = x + sum(y[i] * V[i] for i in range(k))
+        if res <= tol:
+            break
+    return x.reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# FiniteMPS with the lazy-gauge state machine (finitemps.jl:53-169, orthoview.jl:1-143)
+# --------------------------------------------------------------------------------------
+
+class FiniteMPS:
+    def __init__(self, As, normalize=False):
+        """finitemps.jl:143-169: left-to-right QRpos sweep; only CLs[L] set."""
+        As = [np.array(a) for a in As]
+        N = len(As)
+        for i in range(N - 1):
+            As[i], C = leftorth(As[i])
+            if normalize:
+                C = C / np.linalg.norm(C)
+            As[i + 1] = np.einsum("ka,asb->ksb", C, As[i + 1])
+        As[-1], C = leftorth(As[-1])
+        if normalize:
+            C = C / np.linalg.norm(C)
+        self.N = N
+        self.ALs = list(As)
+        self.ARs = [None] * N
+        self.ACs = [None] * N
+        self.CLs = [None] * (N + 1)
+        self.CLs[N] = C
+
+    @classmethod
+    def random(cls, L, d, D, rng, dtype=np.float64, normalize=True):
+        """finitemps.jl:171-207: bond dims min(d^i, D, d^(L-i)), entries uniform[0,1) ('rand')."""
+        dims = [1]
+        for k in range(1, L):
+            dims.append(min(dims[-1] * d, D))
+        dims.append(1)
+        for k in range(L - 1, 0, -1):
+            dims[k] = min(dims[k], dims[k + 1] * d)
+        As = []
+        for i in range(L):
+            t = rng.random((dims[i], d, dims[i + 1]))
+            if np.issubdtype(dtype, np.complexfloating):
+                t = t + 1j * rng.random((dims[i], d, dims[i + 1]))
+            As.append(t.astype(dtype))
+        return cls(As, normalize=normalize)
+
+    def copy(self):
+        o = object.__new__(FiniteMPS)
+        o.N = self.N
+        o.ALs, o.ARs, o.ACs, o.CLs = list(self.ALs), list(self.ARs), list(self.ACs), list(self.CLs)
+        return o
+
+    def __len__(self):
+        return self.N
+
+    # --- views (0-based sites; CR(i) for i in -1..N-1 is the bond right of site i) ---
+    def AL(self, i):  # orthoview.jl:6-9
+        if self.ALs[i] is None:
+            self.CR(i)
+        return self.ALs[i]
+
+    def AR(self, i):  # :27-31
+        if self.ARs[i] is None:
+            self.CR(i - 1)
+        return self.ARs[i]
+
+    def CR(self, i):  # :49-60 ; CLs[i+1] is the bond to the right of site i
+        if self.CLs[i + 1] is None:
+            if i == -1 or self.ALs[i] is not None:
+                C, ar = rightorth(self.AC(i + 1))
+                self.CLs[i + 1], self.ARs[i + 1] = C, ar
+            else:
+                al, C = leftorth(self.AC(i))
+                self.ALs[i], self.CLs[i + 1] = al, C
+        return self.CLs[i + 1]
+
+    def AC(self, i):  # :95-106
+        if self.ACs[i] is None and self.ARs[i] is not None:
+            c = self.CR(i - 1)
+            self.ACs[i] = np.einsum("ka,asb->ksb", c, self.ARs[i])
+        elif self.ACs[i] is None and self.ALs[i] is not None:
+            c = self.CR(i)
+            self.ACs[i] = np.einsum("asb,bk->ask", self.ALs[i], c)
+        return self.ACs[i]
+
+    def _invalidate(self, i):
+        self.ACs = [None] * self.N
+        self.CLs = [None] * (self.N + 1)
+        for k in range(i, self.N):
+            self.ALs[k] = None
+        for k in range(0, i + 1):
+            self.ARs[k] = None
+
+    def set_AC(self, i, vec):  # :108-143
+        if self.ACs[i] is None:
+            if i < self.N - 1:
+                self.AR(i + 1)
+            if i > 0:
+                self.AL(i - 1)
+        self._invalidate(i)
+        if isinstance(vec, tuple):
+            a, b = vec
+            if a.ndim == 2:  # (c, ar)
+                self.CLs[i], self.ARs[i] = a, b
+            else:  # (al, c)
+                self.CLs[i + 1], self.ALs[i] = b, a
+        else:
+            self.ACs[i] = vec
+
+    def norm(self):  # finitemps.jl:467
+        return np.linalg.norm(self.AC(0))
+
+    def bond_dims(self):
+        out = []
+        for i in range(self.N):
+            t = self.ALs[i] if self.ALs[i] is not None else (
+                self.ARs[i] if self.ARs[i] is not None else self.ACs[i])
+            out.append(t.shape[2])
+        return out
+
+
+class FinEnv:
+    """FinEnv.jl:9-145: cache with identity(`is`)-based invalidation."""
+
+    def __init__(self, psi: FiniteMPS, H: MPOHamiltonian):
+        L = len(psi)
+        self.opp = [H[i] for i in range(L)]
+        self.H = H
+        odim = H.odim
+        D0 = psi.AL(0).shape[0]
+        DL = psi.AR(L - 1).shape[2] if psi.ARs[L - 1] is not None else psi.AL(L - 1).shape[2]
+        dt = np.result_type(psi.AL(0).dtype, H[0].dtype)
+        leftstart, rightstart = [], []
+        for i in range(odim):  # FinEnv.jl:49-67
+            ctl = np.einsum("pa,w->pwa", np.eye(D0, dtype=dt), np.ones(H[0].chil[i], dtype=dt))
+            ctr = np.einsum("pa,w->pwa", np.eye(DL, dtype=dt), np.ones(H[L - 1].chir[i], dtype=dt))
+            if i != 0:
+                ctl = np.zeros_like(ctl)
+            if i != odim - 1:
+                ctr = np.zeros_like(ctr)
+            leftstart.append(ctl)
+            rightstart.append(ctr)
+        self.leftenvs = [leftstart] + [None] * L
+        self.rightenvs = [None] * L + [rightstart]
+        self.ldeps = [None] * L
+        self.rdeps = [None] * L
+        self.n_transfers = 0
+
+    def rightenv(self, ind, psi):  # FinEnv.jl:114-129
+        L = len(psi)
+        a = None
+        for i in range(L - 1, ind, -1):
+            if psi.AR(i) is not self.rdeps[i]:
+                a = i
+                break
+        if a is not None:
+            for j in range(a, ind, -1):
+                self.rightenvs[j] = transfer_right(self.rightenvs[j + 1], self.opp[j],
+                                                   psi.AR(j), psi.AR(j))
+                self.rdeps[j] = psi.AR(j)
+                self.n_transfers += 1
+        return self.rightenvs[ind + 1]
+
+    def leftenv(self, ind, psi):  # FinEnv.jl:131-145
+        a = None
+        for i in range(0, ind):
+            if psi.AL(i) is not self.ldeps[i]:
+                a = i
+                break
+        if a is not None:
+            for j in range(a, ind):
+                self.leftenvs[j + 1] = transfer_left(self.leftenvs[j], self.opp[j],
+                                                     psi.AL(j), psi.AL(j))
+                self.ldeps[j] = psi.AL(j)
+                self.n_transfers += 1
+        return self.leftenvs[ind]
+
+
+def calc_galerkin(psi, pos, envs):
+    """toolbox.jl:17-22."""
+    g = dAC(psi.AC(pos), envs.opp[pos], envs.leftenv(pos, psi), envs.rightenv(pos, psi))
+    g = g / np.linalg.norm(g)
+    al = psi.AL(pos)
+    Dl, d, Dr = al.shape
+    M = al.reshape(Dl * d, Dr)
+    gv = g.reshape(Dl * d, -1)
+    out = gv - M @ (M.conj().T @ gv)
+    return float(np.linalg.norm(out))
+
+
+def expectation_value(psi, H, envs):
+    """expval.jl:92-109 : per-site energies of a FiniteMPS."""
+    L = len(psi)
+    ens = np.zeros(L, dtype=np.result_type(psi.AC(0).dtype, H[0].dtype))
+    odim = H.odim
+    for i in range(L):
+        ac = psi.AC(i)
+        GL, GR = envs.leftenv(i, psi), envs.rightenv(i, psi)
+        for (j, k) in H[i].keys():
+            if not ((j == 0 and k != 0) or (k == odim - 1 and j != odim - 1)):
+                continue
+            cur = np.einsum("pwa,asb,bvq,ptq,wtsv->", GL[j], ac, GR[k], np.conj(ac),
+                            H[i].dense(j, k), optimize=True)
+            if not (j == 0 and k == odim - 1):
+                cur = cur / 2
+            ens[i] += cur
+    n = np.linalg.norm(psi.AC(L - 1)) ** 2
+    return ens / n
+
+
+# --------------------------------------------------------------------------------------
+# Drivers (src/algorithms/groundstate/dmrg.jl)
+# --------------------------------------------------------------------------------------
+
+def dmrg(psi, H, tol=1e-12, maxiter=100, eig_tol=1e-12, krylovdim=30, eig_maxiter=100,
+         fixed_matvecs=None, verbose=False, envs=None):
+    """find_groundstate!(psi, H, DMRG())  (dmrg.jl:22-55).  Returns (psi, envs, eps, log)."""
+    psi = psi.copy()
+    envs = FinEnv(psi, H) if envs is None else envs
+    L = len(psi)
+    eps_s = [calc_galerkin(psi, p, envs) for p in range(L)]
+    eps = max(eps_s)
+    log = []
+    for it in range(1, maxiter + 1):
+        eps_s = [0.0] * L
+        for pos in list(range(0, L - 1)) + list(range(L - 1, 0, -1)):
+            GL, GR = envs.leftenv(pos, psi), envs.rightenv(pos, psi)
+            slc = envs.opp[pos]
+            _, vec, _ = eigsolve_sr(lambda x: dAC(x, slc, GL, GR), psi.AC(pos), tol=eig_tol,
+                                    krylovdim=krylovdim, maxiter=eig_maxiter,
+                                    fixed_matvecs=fixed_matvecs)
+            eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs))
+            psi.set_AC(pos, vec)
+        eps = max(eps_s)
+        E = float(np.real(np.sum(expectation_value(psi, H, envs))))
+        log.append((it, E, eps))
+        if verbose:
+            print(f"DMRG {it:3d}: obj = {E:+.12e} err = {eps:.10e}")
+        if eps <= tol:
+            break
+    return psi, envs, eps, log
+
+
+def dmrg2(psi, H, truncdim=None, truncerr=1e-6, tol=1e-12, maxiter=100, eig_tol=1e-12,
+          krylovdim=30, eig_maxiter=100, fixed_matvecs=None, verbose=False):
+    """find_groundstate!(psi, H, DMRG2(trscheme))  (dmrg.jl:80-137)."""
+    psi = psi.copy()
+    envs = FinEnv(psi, H)
+    L = len(psi)
+    log = []
+    eps = np.inf
+    if truncdim is not None:
+        truncerr = None
+    for it in range(1, maxiter + 1):
+        eps_s = [0.0] * L
+
+        def update(pos, ac2):
+            GL, GR = envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi)
+            h1, h2 = envs.opp[pos], envs.opp[pos + 1]
+            _, new, _ = eigsolve_sr(lambda x: dAC2(x, h1, h2, GL, GR), ac2, tol=eig_tol,
+                                    krylovdim=krylovdim, maxiter=eig_maxiter,
+                                    fixed_matvecs=fixed_matvecs)
+            al, s, ar, _ = tsvd(new, truncdim=truncdim, truncerr=truncerr)
+            s = s / np.linalg.norm(s)
+            c = np.diag(s).astype(new.dtype)
+            v = np.einsum("asbr,asm,mn,nbr->", ac2, np.conj(al), np.conj(c), np.conj(ar))
+            eps_s[pos] = max(eps_s[pos], abs(1 - abs(v)))
+            ar3 = np.transpose(ar, (0, 2, 1))  # [k, s2, b]
+            return al, c, ar3
+
+        for pos in range(0, L - 1):
+            ac2 = np.einsum("asm,mrb->asbr", psi.AC(pos), psi.AR(pos + 1))
+            al, c, ar3 = update(pos, ac2)
+            psi.set_AC(pos, (al, c))
+            psi.set_AC(pos + 1, (c, ar3))
+        for pos in range(L - 3, -1, -1):
+            ac2 = np.einsum("asm,mrb->asbr", psi.AL(pos), psi.AC(pos + 1))
+            al, c, ar3 = update(pos, ac2)
+            psi.set_AC(pos + 1, (c, ar3))
+            psi.set_AC(pos, (al, c))
+        eps = max(eps_s)
+        E = float(np.real(np.sum(expectation_value(psi, H, envs))))
+        log.append((it, E, eps))
+        if verbose:
+            print(f"DMRG2 {it:3d}: obj = {E:+.12e} err = {eps:.10e}")
+        if eps <= tol:
+            break
+    return psi, envs, eps, log
+
+
+# --------------------------------------------------------------------------------------
+# InfiniteMPS, uniform gauge, infinite environments, VUMPS
+# (src/states/infinitemps.jl, ortho.jl, src/environments/mpohaminfenv.jl, vumps.jl)
+# --------------------------------------------------------------------------------------
+
+def updatetol(tol_min, tol_max, factor, it, eps):  # dynamictols.jl:50-53
+    return min(max(eps * factor / math.sqrt(it), tol_min), tol_max)
+
+
+def uniform_leftorth(A, C0, tol=1e-14, maxiter=100, eig_miniter=10):
+    """ortho.jl uniform_leftorth! : iterate {optional Arnoldi on flip(TransferMatrix(A, AL));
+    per-site C.A -> QRpos} until ||C0 - C1|| < tol.  A: list of site tensors; returns (AL, CR)
+    with CR[i] the bond right of site i (CR[-1] == CR[n-1])."""
+    n = len(A)
+    CR = [None] * n
+    CR[n - 1] = C0 / np.linalg.norm(C0)
+    AL = [None] * n
+    eps, it = np.inf, 0
+    while True:
+        # eigsolve step
+        if it >= eig_miniter:
+            etol = min(max(eps ** 2, 1e-15), np.inf)
+
+            def tm(v):
+                for i in range(n):
+                    v = transfer_left_bond(v, A[i], AL[i])
+                return v
+            _, vec = eigsolve_lm(tm, CR[n - 1].astype(complex), tol=etol)
+            if not np.iscomplexobj(A[0]):
+                ph = vec.reshape(-1)[np.argmax(np.abs(vec))]
+                vec = np.real(vec * np.conj(ph) / abs(ph))
+            _, CR[n - 1] = qrpos(vec)
+        C0_ = CR[n - 1]
+        # orth step
+        for i in range(n):
+            cprev = CR[(i - 1) % n]
+            AL[i], CR[i] = leftorth(np.einsum("ka,asb->ksb", cprev, A[i]))
+        CR[n - 1] = CR[n - 1] / np.linalg.norm(CR[n - 1])
+        eps = np.linalg.norm(C0_ - CR[n - 1])
+        it += 1
+        if eps < tol or it > maxiter:
+            return AL, CR
+
+
+def uniform_rightorth(A, C0, tol=1e-14, maxiter=100, eig_miniter=10):
+    n = len(A)
+    CR = [None] * n
+    CR[n - 1] = C0 / np.linalg.norm(C0)
+    AR = [None] * n
+    eps, it = np.inf, 0
+    while True:
+        if it >= eig_miniter:
+            etol = max(eps ** 2, 1e-15)
+
+            def tm(v):
+                for i in range(n - 1, -1, -1):
+                    v = transfer_right_bond(v, A[i], AR[i])
+                return v
+            _, vec = eigsolve_lm(tm, CR[n - 1].astype(complex), tol=etol)
+            if not np.iscomplexobj(A[0]):
+                ph = vec.reshape(-1)[np.argmax(np.abs(vec))]
+                vec = np.real(vec * np.conj(ph) / abs(ph))
+            CR[n - 1], _ = lqpos(vec)
+        C0_ = CR[n - 1]
+        for i in range(n - 1, -1, -1):
+            AC = np.einsum("asb,bk->ask", A[i], CR[i])
+            CR[(i - 1) % n], AR[i] = rightorth(AC)
+        CR[n - 1] = CR[n - 1] / np.linalg.norm(CR[n - 1])
+        eps = np.linalg.norm(C0_ - CR[n - 1])
+        it += 1
+        if eps < tol or it > maxiter:
+            return AR, CR
+
+
+class InfiniteMPS:
+    """infinitemps.jl:46-104 ; fields AL, AR, CR (bond right of site i), AC."""
+
+    def __init__(self, AL, AR, CR, AC):
+        self.AL, self.AR, self.CR, self.AC = AL, AR, CR, AC
+
+    def __len__(self):
+        return len(self.AL)
+
+    @classmethod
+    def from_tensors(cls, A, tol=1e-14, maxiter=100):
+        """infinitemps.jl:139-170 : gaugefix!(order = :LR) from generic tensors."""
+        A = [np.array(a) for a in A]
+        D = A[0].shape[0]
+        AL, CR = uniform_leftorth(A, np.eye(D, dtype=A[0].dtype), tol, maxiter)
+        AR, CR = uniform_rightorth(AL, CR[-1], tol, maxiter)
+        AC = [np.einsum("asb,bk->ask", AL[i], CR[i]) for i in range(len(A))]
+        return cls(AL, AR, CR, AC)
+
+    @classmethod
+    def from_AL(cls, AL, C0, tol=1e-14, maxiter=100):
+        """infinitemps.jl:172-186 : gaugefix!(order = :R)."""
+        AL = [np.array(a) for a in AL]
+        AR, CR = uniform_rightorth(AL, C0, tol, maxiter)
+        AC = [np.einsum("asb,bk->ask", AL[i], CR[i]) for i in range(len(AL))]
+        return cls(AL, AR, CR, AC)
+
+    @classmethod
+    def random(cls, d, D, rng, n=1, dtype=np.float64):
+        As = []
+        for _ in range(n):
+            t = rng.random((D, d, D))
+            if np.issubdtype(dtype, np.complexfloating):
+                t = t + 1j * rng.random((D, d, D))
+            As.append(t.astype(dtype))
+        return cls.from_tensors(As)
+
+
+class MPOHamInfEnv:
+    """mpohaminfenv.jl:4-215.  lw[i][site] / rw[i][site], levels 0..odim-1."""
+
+    def __init__(self, psi, H, tol=1e-12, maxiter=100, rng=None):
+        self.H, self.tol, self.maxiter = H, tol, maxiter
+        n, odim = len(psi), H.odim
+        rng = np.random.default_rng(0) if rng is None else rng
+        D = [psi.AL[i].shape[0] for i in range(n)]
+        dt = psi.AL[0].dtype
+        self.lw = [[rng.random((D[s], H[s].chil[i], D[s])).astype(dt) for s in range(n)]
+                   for i in range(odim)]
+        self.rw = [[rng.random((psi.AR[s].shape[2], H[s].chir[i], psi.AR[s].shape[2])).astype(dt)
+                    for s in range(n)] for i in range(odim)]
+        self.recalculate(psi, tol)
+
+    def recalculate(self, psi, tol=None):
+        tol = self.tol if tol is None else tol
+        self._calclw(psi, tol)
+        self._calcrw(psi, tol)
+        self.dependency = psi
+        return self
+
+    def leftenv(self, pos, psi):
+        if self.dependency is not psi:
+            self.recalculate(psi)
+        n = len(psi)
+        return [self.lw[i][pos % n] for i in range(self.H.odim)]
+
+    def rightenv(self, pos, psi):
+        if self.dependency is not psi:
+            self.recalculate(psi)
+        n = len(psi)
+        return [self.rw[i][pos % n] for i in range(self.H.odim)]
+
+    # fixed points of the plain transfer matrices (infinitemps.jl l_LL, r_LL, l_RR, r_RR)
+    @staticmethod
+    def _l_LL(psi, s=0):
+        D = psi.AL[s % len(psi)].shape[0]
+        return np.eye(D, dtype=psi.AL[0].dtype)
+
+    @staticmethod
+    def _r_LL(psi, s):  # C C^dagger of the bond right of site s
+        c = psi.CR[s % len(psi)]
+        return c @ c.conj().T
+
+    @staticmethod
+    def _l_RR(psi, s):  # C^dagger C of the bond LEFT of site s
+        c = psi.CR[(s - 1) % len(psi)]
+        return c.conj().T @ c  # transposed orientation handled in regularize
+
+    @staticmethod
+    def _r_RR(psi, s=-1):
+        D = psi.AR[s % len(psi)].shape[2]
+        return np.eye(D, dtype=psi.AR[0].dtype)
+
+    def _left_cycle(self, idx, psi):  # mpohaminfenv.jl:177-195
+        n, H = len(psi), self.H
+        for s in range(n):
+            acc = np.zeros_like(self.lw[idx][(s + 1) % n])
+            for j in range(idx, -1, -1):
+                if not H[s].contains(j, idx):
+                    continue
+                if H[s].isscal(j, idx):
+                    acc = acc + H[s].Os[(j, idx)] * transfer_left_block(self.lw[j][s], None,
+                                                                        psi.AL[s], psi.AL[s])
+                else:
+                    acc = acc + transfer_left_block(self.lw[j][s], H[s].Os[(j, idx)],
+                                                    psi.AL[s], psi.AL[s])
+            self.lw[idx][(s + 1) % n] = acc
+
+    def _right_cycle(self, idx, psi):  # :197-215
+        n, H = len(psi), self.H
+        for s in range(n - 1, -1, -1):
+            acc = np.zeros_like(self.rw[idx][(s - 1) % n])
+            for j in range(idx, H.odim):
+                if not H[s].contains(idx, j):
+                    continue
+                if H[s].isscal(idx, j):
+                    acc = acc + H[s].Os[(idx, j)] * transfer_right_block(self.rw[j][s], None,
+                                                                         psi.AR[s], psi.AR[s])
+                else:
+                    acc = acc + transfer_right_block(self.rw[j][s], H[s].Os[(idx, j)],
+                                                     psi.AR[s], psi.AR[s])
+            self.rw[idx][(s - 1) % n] = acc
+
+    def _calclw(self, psi, tol):  # :76-123  (site index 0 == reference site 1)
+        n, H, odim = len(psi), self.H, self.H.odim
+        D0 = psi.AL[0].shape[0]
+        dt = psi.AL[0].dtype
+        self.lw[0][0] = np.einsum("pa,w->pwa", np.eye(D0, dtype=dt), np.ones(H[0].chil[0], dtype=dt))
+        if n > 1:
+            self._left_cycle(0, psi)
+        for i in range(1, odim):
+            prev = self.lw[i][0].copy()
+            self.lw[i][0] = np.zeros_like(self.lw[i][0])
+            self._left_cycle(i, psi)   # fills lw[i][1..n-1] and wraps into lw[i][0]
+            if H.isid(i):
+                lvec = self._r_LL(psi, n - 1)   # right fixed point (C C^dag), contracted with v
+                rvec = self._l_LL(psi, 0)
+
+                def op(x):  # x - x*T + regularisation  (transfermatrix.jl:29-33,70-76; linsolve a0=1,a1=-1)
+                    y = x
+                    for s in range(n):
+                        y = transfer_left_block(y, None, psi.AL[s], psi.AL[s])
+                    y = regularize_env(y, lvec, rvec)
+                    return x - y
+                self.lw[i][0] = gmres(op, self.lw[i][0], prev, tol=tol, maxiter=self.maxiter)
+                if n > 1:
+                    self._left_cycle(i, psi)
+                for s in range(n):  # :103-107 subtract fixed-point projection
+                    r = self._r_LL(psi, s - 1)
+                    coef = np.einsum("xwy,yx->w", self.lw[i][s], r)
+                    self.lw[i][s] = self.lw[i][s] - np.einsum("w,pq->pwq", coef, self._l_LL(psi, s))
+            else:
+                if all(H[s].contains(i, i) for s in range(n)):
+                    def op(x):
+                        y = x
+                        for s in range(n):
+                            O = H[s].Os[(i, i)]
+                            if np.isscalar(O):
+                                y = O * transfer_left_block(y, None, psi.AL[s], psi.AL[s])
+                            else:
+                                y = transfer_left_block(y, O, psi.AL[s], psi.AL[s])
+                        return x - y
+                    self.lw[i][0] = gmres(op, self.lw[i][0], prev, tol=tol, maxiter=self.maxiter)
+                if n > 1:
+                    self._left_cycle(i, psi)
+
+    def _calcrw(self, psi, tol):  # :125-175
+        n, H, odim = len(psi), self.H, self.H.odim
+        DL = psi.AR[n - 1].shape[2]
+        dt = psi.AR[0].dtype
+        self.rw[odim - 1][n - 1] = np.einsum("pa,w->pwa", np.eye(DL, dtype=dt),
+                                             np.ones(H[n - 1].chir[odim - 1], dtype=dt))
+        if n > 1:
+            self._right_cycle(odim - 1, psi)
+        for i in range(odim - 2, -1, -1):
+            prev = self.rw[i][n - 1].copy()
+            self.rw[i][n - 1] = np.zeros_like(self.rw[i][n - 1])
+            self._right_cycle(i, psi)
+            if H.isid(i):
+                lvec = self._l_RR(psi, 0)   # C^dag C of the bond left of site 0
+                rvec = self._r_RR(psi, n - 1)
+
+                def op(x):
+                    y = x
+                    for s in range(n - 1, -1, -1):
+                        y = transfer_right_block(y, None, psi.AR[s], psi.AR[s])
+                    coef = np.einsum("xwy,xy->w", y, np.conj(lvec))
+                    y = y - np.einsum("w,pq->pwq", coef, rvec)
+                    return x - y
+                self.rw[i][n - 1] = gmres(op, self.rw[i][n - 1], prev, tol=tol, maxiter=self.maxiter)
+                if n > 1:
+                    self._right_cycle(i, psi)
+                for s in range(n):
+                    l = self._l_RR(psi, s + 1)
+                    coef = np.einsum("xwy,xy->w", self.rw[i][s], np.conj(l))
+                    self.rw[i][s] = self.rw[i][s] - np.einsum("w,pq->pwq", coef, self._r_RR(psi, s))
+            else:
+                if all(H[s].contains(i, i) for s in range(n)):
+                    def op(x):
+                        y = x
+                        for s in range(n - 1, -1, -1):
+                            O = H[s].Os[(i, i)]
+                            if np.isscalar(O):
+                                y = O * transfer_right_block(y, None, psi.AR[s], psi.AR[s])
+                            else:
+                                y = transfer_right_block(y, O, psi.AR[s], psi.AR[s])
+                        return x - y
+                    self.rw[i][n - 1] = gmres(op, self.rw[i][n - 1], prev, tol=tol, maxiter=self.maxiter)
+                if n > 1:
+                    self._right_cycle(i, psi)
+
+
+def calc_galerkin_inf(psi, envs):
+    out = 0.0
+    for loc in range(len(psi)):
+        GL, GR = envs.leftenv(loc, psi), envs.rightenv(loc, psi)
+        g = dAC(psi.AC[loc], envs.H[loc], GL, GR)
+        g = g / np.linalg.norm(g)
+        al = psi.AL[loc]
+        M = al.reshape(-1, al.shape[2])
+        gv = g.reshape(M.shape[0], -1)
+        out = max(out, float(np.linalg.norm(gv - M @ (M.conj().T @ gv))))
+    return out
+
+
+def expectation_value_inf(psi, H, envs):
+    """expval.jl:111-124 : energy density per site of an InfiniteMPS."""
+    n, odim = len(psi), H.odim
+    ens = np.zeros(n, dtype=np.result_type(psi.AL[0].dtype, H[0].dtype))
+    for i in range(n):
+        GL = envs.leftenv(i, psi)
+        r = psi.CR[i] @ psi.CR[i].conj().T
+        for j in range(odim - 1, -1, -1):
+            if not H[i].contains(j, odim - 1):
+                continue
+            O = H[i].Os[(j, odim - 1)]
+            if np.isscalar(O):
+                apl = O * transfer_left_block(GL[j], None, psi.AL[i], psi.AL[i])
+            else:
+                apl = transfer_left_block(GL[j], O, psi.AL[i], psi.AL[i])
+            ens[i] += np.einsum("xwy,yx->", apl, r)
+    return ens
+
+
+def regauge(AC, C):
+    """ortho.jl:127-131."""
+    Dl, d, Dr = AC.shape
+    Qac, _ = qrpos(AC.reshape(Dl * d, Dr))
+    Qc, _ = qrpos(C)
+    return (Qac @ Qc.conj().T).reshape(Dl, d, Dr)
+
+
+def vumps(psi, H, tol=1e-12, maxiter=100, krylovdim=30, verbose=False, fixed_matvecs=None):
+    """find_groundstate(psi::InfiniteMPS, H, VUMPS())  (vumps.jl:29-92) with the Defaults of
+    defaults.jl:38-57 (dynamic tolerances)."""
+    envs = MPOHamInfEnv(psi, H)
+    eps = calc_galerkin_inf(psi, envs)
+    log = []
+    n = len(psi)
+    for it in range(1, maxiter + 1):
+        eig_tol = updatetol(1e-12, 1e-5, 1e-5, it, eps)
+        newAL = []
+        for loc in range(n):
+            GL, GR = envs.leftenv(loc, psi), envs.rightenv(loc, psi)
+            slc = H[loc]
+            _, AC, _ = eigsolve_sr(lambda x: dAC(x, slc, GL, GR), psi.AC[loc], tol=eig_tol,
+                                   krylovdim=krylovdim, fixed_matvecs=fixed_matvecs)
+            GL1 = envs.leftenv(loc + 1, psi)
+            _, C, _ = eigsolve_sr(lambda x: dC(x, GL1, GR), psi.CR[loc], tol=eig_tol,
+                                  krylovdim=krylovdim, fixed_matvecs=fixed_matvecs)
+            newAL.append(regauge(AC, C))
+        gauge_tol = updatetol(1e-14, 1e-5, 1e-8, it, eps)
+        psi = InfiniteMPS.from_AL(newAL, psi.CR[n - 1], tol=gauge_tol)
+        env_tol = updatetol(1e-12, 1e-5, 1e-5, it, eps)
+        envs.recalculate(psi, env_tol)
+        eps = calc_galerkin_inf(psi, envs)
+        E = float(np.real(np.sum(expectation_value_inf(psi, H, envs))))
+        log.append((it, E, eps))
+        if verbose:
+            print(f"VUMPS {it:3d}: obj = {E:+.12e} err = {eps:.10e}")
+        if eps <= tol:
+            break
+    return psi, envs, eps, log
