@@ -1,0 +1,146 @@
+/* libmpsk -- C ABI of the MI355X-native (gfx950) DMRG / VUMPS hot path.
+ *
+ * This is the drop-in boundary for the per-site inner loop of stecrotti/MPSKit.jl v0.10.2: every
+ * entry point replaces one Julia method of the reference (cited as file:line relative to the
+ * reference root) and is what a `ccall((:mpsk_xxx, libmpsk), Cint, ...)` shim binds.  The
+ * reference itself has no FFI: the seams are the multiple-dispatch methods listed below
+ * (SURVEY.md section 8b); INTEGRATION.md shows the Julia-side overloads.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; mpsk_last_error() gives the
+ *    thread-local message.  No exceptions or longjmp cross the boundary.
+ *  - all tensor arguments are DEVICE pointers to fp64, column-major ("Fortran", TensorKit's
+ *    trivial-sector storage) in TensorKit index order:
+ *        MPS tensor      x [Dl, d, Dr]             (V_l (x) P <- V_r)        src/states/abstractmps.jl:30-33
+ *        two-site tensor x2[Dl, d, Dr, d]          (V_l (x) P <- V_r (x) P)  src/algorithms/groundstate/dmrg.jl:92
+ *        bond matrix     c [Dl, Dr]
+ *        environment     G [W][Dbra, Dket]  = W column-major slabs, slab (off_i + k) holding
+ *                        GL[i][:, k, :] of the reference's Vector of [D, chi_i, D] tensors
+ *                        (src/environments/FinEnv.jl:49-59, mpohaminfenv.jl:25-30); W = sum_i chi_i.
+ *    The host owns all device memory (any allocator: hipMalloc, torch, AMDGPU.jl ROCArray);
+ *    mpsk_malloc & co. are provided for hosts that have none.
+ *  - one mpsk_ctx = one device + one HIP stream + a private workspace.  Calls on a ctx are
+ *    asynchronous on its stream; functions that return a host scalar synchronise.  Distinct
+ *    ctxs may be driven concurrently from distinct host threads (the reference applies its
+ *    operators from several Julia tasks: vumps.jl:39-49,78-86).
+ *  - dtype: this round implements MPSK_F64 (real fp64 MFMA path).  MPSK_C128 is reserved and
+ *    returns MPSK_ERR_UNSUPPORTED.
+ */
+#ifndef MPSK_H
+#define MPSK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpsk_ctx mpsk_ctx;
+typedef struct mpsk_mposlice mpsk_mposlice;
+
+enum { MPSK_F64 = 0, MPSK_C128 = 1 };
+enum { MPSK_OK = 0, MPSK_ERR_INVALID = 1, MPSK_ERR_HIP = 2, MPSK_ERR_UNSUPPORTED = 3, MPSK_ERR_NOMEM = 4 };
+/* MPO block kinds, src/operators/sparsempo/sparseslice.jl:74-106 (contains / isscal) */
+enum { MPSK_BLOCK_ZERO = 0, MPSK_BLOCK_SCALAR = 1, MPSK_BLOCK_DENSE = 2 };
+
+int mpsk_version(void);
+const char* mpsk_last_error(void);
+
+/* ---- context ---------------------------------------------------------------------------- */
+int mpsk_ctx_create(int device, mpsk_ctx** out);
+int mpsk_ctx_destroy(mpsk_ctx* ctx);
+int mpsk_ctx_set_stream(mpsk_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = default */
+int mpsk_ctx_synchronize(mpsk_ctx* ctx);
+int mpsk_ctx_workspace_reserve(mpsk_ctx* ctx, size_t bytes);   /* pre-size the private workspace */
+/* tile override for benchmarking the GEMM core (0,0 restores the heuristic) */
+int mpsk_ctx_force_tile(mpsk_ctx* ctx, int bm, int bn);
+
+/* ---- memory helpers (optional) ------------------------------------------------------------ */
+int mpsk_malloc(mpsk_ctx* ctx, size_t bytes, void** dptr);
+int mpsk_free(mpsk_ctx* ctx, void* dptr);
+int mpsk_memcpy_h2d(mpsk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int mpsk_memcpy_d2h(mpsk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int mpsk_memcpy_d2d(mpsk_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- MPO slice: SparseMPOSlice, src/operators/sparsempo/sparseslice.jl:13-27 ----------------
+ * odim x odim blocks (column-major tables: entry (i,j) at i + odim*j).  chi_l[i] / chi_r[j] are
+ * the MPO bond dimensions of level i (left) / j (right).  kind: MPSK_BLOCK_*.  scalars[i,j]: value of a
+ * scalar block (c * identity, needs chi_l[i] == chi_r[j]).  blocks[i,j]: HOST pointer to a dense
+ * block O[chi_l[i], d, d, chi_r[j]] column-major, index order [w, t(out), s(in), v]
+ * (docs/src/man/intro.md:78-83, derivatives.jl:97), or NULL. */
+int mpsk_mposlice_create(mpsk_ctx* ctx, int dtype, int odim, const int32_t* chi_l, const int32_t* chi_r,
+                         int d, const int32_t* kind, const double* scalars, const void* const* blocks,
+                         mpsk_mposlice** out);
+int mpsk_mposlice_destroy(mpsk_mposlice* s);
+int mpsk_mposlice_dims(const mpsk_mposlice* s, int* Wl, int* Wr, int* d);
+
+/* ---- effective-Hamiltonian matvecs: src/algorithms/derivatives.jl ---------------------------
+ * mpsk_dAC  == dAC(x, H::SparseMPOSlice, leftenv, rightenv)   derivatives.jl:77-104
+ *   y[p,t,q] = sum GL[w][p,a] x[a,s,b] O[w,t,s,v] GR[v][b,q]
+ *   GL: Wl slabs [Dlo, Dl]   (Dlo = number of output rows held by this rank; == Dl unsharded)
+ *   GR: Wr slabs [Dr, Dr];  x: [Dl, d, Dr];  y: [Dlo, d, Dr]. */
+int mpsk_dAC(mpsk_ctx* ctx, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL,
+             const void* GR, const void* x, void* y);
+/* mpsk_dC == dC(x, leftenv::Vector, rightenv::Vector)   derivatives.jl:171-193
+ *   y[p,q] = sum_w GL[w][p,a] c[a,b] GR[w][b,q] */
+int mpsk_dC(mpsk_ctx* ctx, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
+            const void* c, void* y);
+/* mpsk_dAC2 == dAC2(x, h1, h2, leftenv, rightenv)   derivatives.jl:119-158
+ *   x2, y2: [Dl, d1, Dr, d2] with (d1, d2) the physical dims of H1 / H2 */
+int mpsk_dAC2(mpsk_ctx* ctx, const mpsk_mposlice* H1, const mpsk_mposlice* H2, int Dlo, int Dl, int Dr,
+              const void* GL, const void* GR, const void* x2, void* y2);
+
+/* ---- transfer matrices / environment updates: src/transfermatrix/transfer.jl ---------------
+ * mpsk_transfer_left == transfer_left(vec, ham::SparseMPOSlice, A, Ab)   transfer.jl:166-211
+ *   GLout[v][q,b] = sum GLin[w][p,a] A[a,s,b] O[w,t,s,v] conj(Ab[p,t,q])
+ *   GLin: Wl slabs [Dlb, Dl]; A: [Dl,d,Dr]; Ab: [Dlb,d,Drb]; GLout: Wr slabs [Drb, Dr]
+ * mpsk_transfer_right == transfer_right(vec, ham, A, Ab)                  transfer.jl:212-259
+ *   GRout[w][a,p] = sum A[a,s,b] O[w,t,s,v] conj(Ab[p,t,q]) GRin[v][b,q]
+ *   GRin: Wr slabs [Dr, Drb]; GRout: Wl slabs [Dl, Dlb]
+ * H == NULL: pass-through legs, W independent slabs (transfer.jl:18-25,38-45,66-75). */
+int mpsk_transfer_left(mpsk_ctx* ctx, const mpsk_mposlice* H, int W, int d, int Dl, int Dr, int Dlb,
+                       int Drb, const void* GLin, const void* A, const void* Ab, void* GLout);
+int mpsk_transfer_right(mpsk_ctx* ctx, const mpsk_mposlice* H, int W, int d, int Dl, int Dr, int Dlb,
+                        int Drb, const void* A, const void* Ab, const void* GRin, void* GRout);
+/* regularize!(v, lvec, rvec)   src/transfermatrix/transfermatrix.jl:70-76
+ *   v[w] -= <lvec^T, v[w]> * rvec  for each of the W slabs [D1, D2]; lvec: [D2, D1]; rvec: [D1, D2] */
+int mpsk_regularize(mpsk_ctx* ctx, int W, int D1, int D2, void* v, const void* lvec, const void* rvec);
+
+/* ---- gauge steps: TensorKit leftorth!(QRpos) / rightorth!(LQpos) / tsvd! ----------------------
+ * call sites: src/states/orthoview.jl:52,56 ; finitemps.jl:149 ; ortho.jl:128-136 ; dmrg.jl:96 */
+/* A (m x n, m >= n, lda) = Q (m x n, ldq) * R (n x n upper, ldr), diag(R) > 0.  A is not modified. */
+int mpsk_qrpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr);
+/* A (m x n, m <= n) = L (m x m lower) * Q (m x n), diag(L) > 0 */
+int mpsk_lqpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq);
+/* thin SVD of theta (m x n): theta = U diag(S) Vh, S descending.  U: m x kmax, S: kmax, Vh: kmax x n
+ * buffers with kmax = min(m, n).  Truncation (TensorKit truncdim & truncerr, dmrg.jl:75,96):
+ * keep at most max_keep (<= 0: no limit) values and drop the tail while
+ * ||S_dropped||_2 <= trunc_err * ||S||_2.  *kept / *disc_norm are written on the host (sync). */
+int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, int ldu, void* S, void* Vh,
+              int ldv, int max_keep, double trunc_err, int* kept, double* disc_norm);
+/* general column-major product C = alpha op(A) op(B) + beta C for the small gauge products
+ * AC = AL*C, AC = C*AR, theta = AC*AR, AL = Q_AC*Q_C'  (orthoview.jl:99,103; dmrg.jl:92; ortho.jl:130) */
+int mpsk_gemm(mpsk_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const void* A,
+              int64_t lda, const void* B, int64_t ldb, double beta, void* C, int64_t ldc);
+
+/* ---- Krylov vector protocol (VectorInterface: inner / add!! / scale!! / zerovector) -----------
+ * KrylovKit needs these of the iterate type (quasiparticle_state.jl:357-411 is the in-repo example). */
+int mpsk_vdot(mpsk_ctx* ctx, int64_t n, const void* x, const void* y, double* host_out);
+int mpsk_vnrm2(mpsk_ctx* ctx, int64_t n, const void* x, double* host_out);
+int mpsk_vaxpby(mpsk_ctx* ctx, int64_t n, double alpha, const void* x, double beta, void* y);
+int mpsk_vscal(mpsk_ctx* ctx, int64_t n, double alpha, void* x);
+int mpsk_vcopy(mpsk_ctx* ctx, int64_t n, const void* x, void* y);
+int mpsk_vzero(mpsk_ctx* ctx, int64_t n, void* x);
+/* fused Gram-Schmidt helpers: xs = HOST array of k device pointers.
+ *   mpsk_vmultidot : host_out[j] = <xs[j], y>                       (one sync for k dots)
+ *   mpsk_vgs_step  : h = [<xs[j], y>]_j ; y -= sum_j h[j] xs[j] ; host_out[j] = h[j]
+ *                    (coefficients stay on the device between the two kernels) */
+int mpsk_vmultidot(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const void* y, double* host_out);
+int mpsk_vgs_step(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* y, double* host_out);
+/* y = sum_j coefs[j] xs[j]   (Ritz vector assembly) */
+int mpsk_vlincomb(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPSK_H */

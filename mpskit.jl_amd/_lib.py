@@ -1,0 +1,100 @@
+"""ctypes binding of libmpsk.so (the C ABI declared in include/mpsk.h).
+
+This is the executable twin of the Julia `ccall` shim described in INTEGRATION.md: every
+function below is bound with exactly the argument list a `ccall((:mpsk_xxx, libmpsk), Cint, ...)`
+would use.  There is NO CPU fallback: if the shared library is missing or a call fails the
+product path raises (`MpskError`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpsk.so")
+
+
+class MpskError(RuntimeError):
+    pass
+
+
+_lib = None
+
+c_void_pp = C.POINTER(C.c_void_p)
+c_int32_p = C.POINTER(C.c_int32)
+c_double_p = C.POINTER(C.c_double)
+
+# name -> argtypes   (restype is always int except where noted)
+SIGNATURES = {
+    "mpsk_ctx_create": [C.c_int, c_void_pp],
+    "mpsk_ctx_destroy": [C.c_void_p],
+    "mpsk_ctx_set_stream": [C.c_void_p, C.c_void_p],
+    "mpsk_ctx_synchronize": [C.c_void_p],
+    "mpsk_ctx_workspace_reserve": [C.c_void_p, C.c_size_t],
+    "mpsk_ctx_force_tile": [C.c_void_p, C.c_int, C.c_int],
+    "mpsk_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
+    "mpsk_free": [C.c_void_p, C.c_void_p],
+    "mpsk_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "mpsk_memcpy_d2h": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "mpsk_memcpy_d2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "mpsk_mposlice_create": [C.c_void_p, C.c_int, C.c_int, c_int32_p, c_int32_p, C.c_int, c_int32_p,
+                             c_double_p, c_void_pp, c_void_pp],
+    "mpsk_mposlice_destroy": [C.c_void_p],
+    "mpsk_mposlice_dims": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "mpsk_dAC": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                 C.c_void_p],
+    "mpsk_dC": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                C.c_void_p],
+    "mpsk_dAC2": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_void_p],
+    "mpsk_transfer_left": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mpsk_transfer_right": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mpsk_regularize": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mpsk_qrpos": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "mpsk_lqpos": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "mpsk_tsvd": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                  C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p],
+    "mpsk_gemm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
+                  C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64],
+    "mpsk_vdot": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, c_double_p],
+    "mpsk_vnrm2": [C.c_void_p, C.c_int64, C.c_void_p, c_double_p],
+    "mpsk_vaxpby": [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_double, C.c_void_p],
+    "mpsk_vscal": [C.c_void_p, C.c_int64, C.c_double, C.c_void_p],
+    "mpsk_vcopy": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "mpsk_vzero": [C.c_void_p, C.c_int64, C.c_void_p],
+    "mpsk_vmultidot": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p],
+    "mpsk_vgs_step": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p],
+    "mpsk_vlincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, c_double_p, C.c_void_p],
+}
+# symbols without the (ctx, ...) -> int shape
+EXTRA_SYMBOLS = ["mpsk_version", "mpsk_last_error"]
+
+
+def load():
+    """dlopen libmpsk.so and attach the prototypes.  Raises MpskError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpskError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.mpsk_version.restype = C.c_int
+    lib.mpsk_version.argtypes = []
+    lib.mpsk_last_error.restype = C.c_char_p
+    lib.mpsk_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mpsk_last_error().decode("utf-8", "replace")
+        raise MpskError(f"{what} failed (code {rc}): {msg}")

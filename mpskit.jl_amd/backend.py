@@ -1,0 +1,344 @@
+"""Device plumbing above the C ABI: a context bound to a torch CUDA(HIP) device/stream, device
+tensors (torch is used ONLY as the allocator / stream / collective provider -- all arithmetic is
+libmpsk's hand-written HIP) and thin typed wrappers over the mpsk_* entry points.
+
+Layout: every tensor is a flat fp64 torch tensor holding the column-major (TensorKit) data;
+`DTensor.shape` carries the logical index order, e.g. (Dl, d, Dr).  Environments are stored as
+(W, Dbra, Dket) = W column-major slabs (include/mpsk.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import MpskError, check
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class DTensor:
+    """Flat device buffer + logical column-major shape."""
+    __slots__ = ("buf", "shape")
+
+    def __init__(self, buf, shape):
+        self.buf = buf
+        self.shape = tuple(int(s) for s in shape)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        t = DTensor(self.buf, shape)
+        assert t.size == self.size, (self.shape, shape)
+        return t
+
+
+class Backend:
+    """One mpsk_ctx on one GPU.  Raises MpskError when the HIP library or a GPU is missing."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise MpskError("no HIP device visible: the mpskit.jl_amd product path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        check(self.lib.mpsk_ctx_create(device, C.byref(h)), "mpsk_ctx_create")
+        self.ctx = h
+        self.bind_stream()
+
+    def bind_stream(self):
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.mpsk_ctx_set_stream(self.ctx, C.c_void_p(s)), "mpsk_ctx_set_stream")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mpsk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def synchronize(self):
+        check(self.lib.mpsk_ctx_synchronize(self.ctx), "mpsk_ctx_synchronize")
+
+    # ---- memory ---------------------------------------------------------------------------
+    def empty(self, *shape):
+        torch = _torch()
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        n = 1
+        for s in shape:
+            n *= int(s)
+        return DTensor(torch.empty(max(n, 1), dtype=torch.float64, device=self.device), shape)
+
+    def zeros(self, *shape):
+        t = self.empty(*shape)
+        t.buf.zero_()
+        return t
+
+    def upload(self, a, shape=None):
+        """host ndarray (logical index order) -> device column-major."""
+        torch = _torch()
+        a = np.asarray(a)
+        if np.iscomplexobj(a):
+            if np.abs(a.imag).max(initial=0.0) > 0:
+                raise MpskError("complex128 tensors are not supported by the fp64 device path (MPSK_C128 reserved)")
+            a = a.real
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        flat = np.ravel(a, order="F")
+        buf = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
+        if buf.numel() == 0:
+            buf = torch.empty(1, dtype=torch.float64, device=self.device)
+        return DTensor(buf, a.shape if shape is None else shape)
+
+    def download(self, t: DTensor):
+        flat = t.buf[: t.size].cpu().numpy()
+        return flat.reshape(t.shape, order="F").copy()
+
+    def upload_env(self, blocks):
+        """reference env = list of [Dbra, chi_i, Dket] arrays -> device (W, Dbra, Dket) slabs."""
+        slabs = []
+        for b in blocks:
+            b = np.asarray(b)
+            for k in range(b.shape[1]):
+                slabs.append(b[:, k, :])
+        return self._upload_slabs(slabs)
+
+    def _upload_slabs(self, slabs):
+        torch = _torch()
+        flat = np.concatenate([np.ravel(np.asarray(s, dtype=np.float64), order="F") for s in slabs])
+        buf = torch.from_numpy(flat).to(self.device)
+        return DTensor(buf, (len(slabs),) + tuple(slabs[0].shape))
+
+    def download_env(self, t: DTensor, chis):
+        W, Db, Dk = t.shape
+        flat = t.buf[: t.size].cpu().numpy()
+        slabs = [flat[w * Db * Dk:(w + 1) * Db * Dk].reshape((Db, Dk), order="F") for w in range(W)]
+        out, o = [], 0
+        for chi in chis:
+            out.append(np.stack(slabs[o:o + chi], axis=1))
+            o += chi
+        return out
+
+    def copy(self, t: DTensor):
+        return DTensor(t.buf.clone(), t.shape)
+
+    # ---- MPO slices -----------------------------------------------------------------------
+    def mposlice(self, odim, d, chil, chir, blocks):
+        """blocks: {(i, j): scalar | ndarray [chi_i, d, d, chi_j]} (0-based levels)."""
+        return DeviceMPOSlice(self, odim, d, chil, chir, blocks)
+
+    # ---- hot-path operators ----------------------------------------------------------------
+    def dAC(self, H, GL: DTensor, GR: DTensor, x: DTensor, out: DTensor = None):
+        Dl, d, Dr = x.shape
+        Wl, Dlo, Dl2 = GL.shape
+        assert Dl2 == Dl and GR.shape == (H.Wr, Dr, Dr) and Wl == H.Wl and d == H.d, (GL.shape, GR.shape, x.shape)
+        y = self.empty(Dlo, d, Dr) if out is None else out
+        check(self.lib.mpsk_dAC(self.ctx, H.handle, Dlo, Dl, Dr, GL.ptr, GR.ptr, x.ptr, y.ptr), "mpsk_dAC")
+        return y
+
+    def dC(self, GL: DTensor, GR: DTensor, c: DTensor, out: DTensor = None):
+        Dl, Dr = c.shape
+        W, Dlo, _ = GL.shape
+        assert GR.shape == (W, Dr, Dr)
+        y = self.empty(Dlo, Dr) if out is None else out
+        check(self.lib.mpsk_dC(self.ctx, W, Dlo, Dl, Dr, GL.ptr, GR.ptr, c.ptr, y.ptr), "mpsk_dC")
+        return y
+
+    def dAC2(self, H1, H2, GL: DTensor, GR: DTensor, x2: DTensor, out: DTensor = None):
+        Dl, d1, Dr, d2 = x2.shape
+        Wl, Dlo, _ = GL.shape
+        assert GR.shape == (H2.Wr, Dr, Dr) and Wl == H1.Wl
+        y = self.empty(Dlo, d1, Dr, d2) if out is None else out
+        check(self.lib.mpsk_dAC2(self.ctx, H1.handle, H2.handle, Dlo, Dl, Dr, GL.ptr, GR.ptr, x2.ptr, y.ptr),
+              "mpsk_dAC2")
+        return y
+
+    def transfer_left(self, H, GLin: DTensor, A: DTensor, Ab: DTensor, out: DTensor = None):
+        Dl, d, Dr = A.shape
+        Dlb, _, Drb = Ab.shape
+        W = GLin.shape[0]
+        Wout = H.Wr if H is not None else W
+        y = self.empty(Wout, Drb, Dr) if out is None else out
+        check(self.lib.mpsk_transfer_left(self.ctx, H.handle if H is not None else None, W, d, Dl, Dr, Dlb, Drb,
+                                          GLin.ptr, A.ptr, Ab.ptr, y.ptr), "mpsk_transfer_left")
+        return y
+
+    def transfer_right(self, H, GRin: DTensor, A: DTensor, Ab: DTensor, out: DTensor = None):
+        Dl, d, Dr = A.shape
+        Dlb, _, Drb = Ab.shape
+        W = GRin.shape[0]
+        Wout = H.Wl if H is not None else W
+        y = self.empty(Wout, Dl, Dlb) if out is None else out
+        check(self.lib.mpsk_transfer_right(self.ctx, H.handle if H is not None else None, W, d, Dl, Dr, Dlb, Drb,
+                                           A.ptr, Ab.ptr, GRin.ptr, y.ptr), "mpsk_transfer_right")
+        return y
+
+    def regularize(self, v: DTensor, lvec: DTensor, rvec: DTensor):
+        W, D1, D2 = v.shape
+        check(self.lib.mpsk_regularize(self.ctx, W, D1, D2, v.ptr, lvec.ptr, rvec.ptr), "mpsk_regularize")
+        return v
+
+    def gemm(self, A: DTensor, B: DTensor, transA=False, transB=False, alpha=1.0, beta=0.0, out: DTensor = None,
+             m=None, n=None, k=None, lda=None, ldb=None, ldc=None):
+        """C = alpha op(A) op(B) + beta C on 2-D column-major views (leading dims default to rows)."""
+        ar, ac = A.shape
+        br, bc = B.shape
+        M = (ac if transA else ar) if m is None else m
+        K = (ar if transA else ac) if k is None else k
+        N = (br if transB else bc) if n is None else n
+        c = self.empty(M, N) if out is None else out
+        check(self.lib.mpsk_gemm(self.ctx, int(transA), int(transB), M, N, K, float(alpha), A.ptr,
+                                 ar if lda is None else lda, B.ptr, br if ldb is None else ldb, float(beta),
+                                 c.ptr, M if ldc is None else ldc), "mpsk_gemm")
+        return c
+
+    # ---- gauge -------------------------------------------------------------------------------
+    def qrpos(self, A: DTensor):
+        m, n = A.shape
+        k = min(m, n)
+        Q, R = self.empty(m, k), self.empty(k, n)
+        check(self.lib.mpsk_qrpos(self.ctx, m, n, A.ptr, m, Q.ptr, m, R.ptr, k), "mpsk_qrpos")
+        return Q, R
+
+    def lqpos(self, A: DTensor):
+        m, n = A.shape
+        k = min(m, n)
+        L, Q = self.empty(m, k), self.empty(k, n)
+        check(self.lib.mpsk_lqpos(self.ctx, m, n, A.ptr, m, L.ptr, m, Q.ptr, k), "mpsk_lqpos")
+        return L, Q
+
+    def tsvd(self, theta: DTensor, max_keep=0, trunc_err=0.0):
+        m, n = theta.shape
+        kmax = min(m, n)
+        U, S, Vh = self.empty(m, kmax), self.empty(kmax), self.empty(kmax, n)
+        kept, disc = C.c_int(0), C.c_double(0.0)
+        check(self.lib.mpsk_tsvd(self.ctx, m, n, theta.ptr, m, U.ptr, m, S.ptr, Vh.ptr, kmax, int(max_keep),
+                                 float(trunc_err), C.byref(kept), C.byref(disc)), "mpsk_tsvd")
+        return U, S, Vh, kept.value, disc.value
+
+    # ---- vectors -----------------------------------------------------------------------------
+    def _ptrs(self, xs):
+        arr = (C.c_void_p * len(xs))(*[x.ptr for x in xs])
+        return arr
+
+    def dot(self, x: DTensor, y: DTensor):
+        out = C.c_double()
+        check(self.lib.mpsk_vdot(self.ctx, x.size, x.ptr, y.ptr, C.byref(out)), "mpsk_vdot")
+        return out.value
+
+    def norm(self, x: DTensor):
+        out = C.c_double()
+        check(self.lib.mpsk_vnrm2(self.ctx, x.size, x.ptr, C.byref(out)), "mpsk_vnrm2")
+        return out.value
+
+    def axpby(self, alpha, x: DTensor, beta, y: DTensor):
+        check(self.lib.mpsk_vaxpby(self.ctx, x.size, float(alpha), x.ptr, float(beta), y.ptr), "mpsk_vaxpby")
+        return y
+
+    def scal(self, alpha, x: DTensor):
+        check(self.lib.mpsk_vscal(self.ctx, x.size, float(alpha), x.ptr), "mpsk_vscal")
+        return x
+
+    def multidot(self, xs, y: DTensor):
+        out = (C.c_double * len(xs))()
+        check(self.lib.mpsk_vmultidot(self.ctx, y.size, len(xs), self._ptrs(xs), y.ptr, out), "mpsk_vmultidot")
+        return np.array(out[:])
+
+    def gs_step(self, xs, y: DTensor):
+        out = (C.c_double * len(xs))()
+        check(self.lib.mpsk_vgs_step(self.ctx, y.size, len(xs), self._ptrs(xs), y.ptr, out), "mpsk_vgs_step")
+        return np.array(out[:])
+
+    def lincomb(self, xs, coefs, out: DTensor = None):
+        y = self.empty(xs[0].shape) if out is None else out
+        cf = (C.c_double * len(xs))(*[float(c) for c in coefs])
+        check(self.lib.mpsk_vlincomb(self.ctx, y.size, len(xs), self._ptrs(xs), cf, y.ptr), "mpsk_vlincomb")
+        return y
+
+
+class DeviceMPOSlice:
+    """Device-side SparseMPOSlice (sparseslice.jl:13-27): keeps the host block table for the
+    host-side logic (keys / isscal / contains) and an mpsk_mposlice handle for the kernels."""
+
+    def __init__(self, be: Backend, odim, d, chil, chir, blocks):
+        self.be = be
+        self.odim, self.d = int(odim), int(d)
+        self.chil, self.chir = [int(c) for c in chil], [int(c) for c in chir]
+        self.Wl, self.Wr = sum(self.chil), sum(self.chir)
+        self.blocks = dict(blocks)
+        n = self.odim
+        kind = (C.c_int32 * (n * n))()
+        scal = (C.c_double * (n * n))()
+        ptrs = (C.c_void_p * (n * n))()
+        keep = []
+        for (i, j), v in self.blocks.items():
+            if np.isscalar(v):
+                if np.iscomplexobj(v) and complex(v).imag != 0:
+                    raise MpskError("complex MPO entries are not supported by the fp64 device path")
+                if v == 0:
+                    continue
+                kind[i + n * j] = 1
+                scal[i + n * j] = float(np.real(v))
+            else:
+                a = np.asarray(v)
+                if np.iscomplexobj(a):
+                    if np.abs(a.imag).max() > 0:
+                        raise MpskError("complex MPO entries are not supported by the fp64 device path")
+                    a = a.real
+                a = np.asfortranarray(a, dtype=np.float64)
+                assert a.shape == (self.chil[i], d, d, self.chir[j]), (a.shape, i, j)
+                flat = np.ravel(a, order="F").copy()
+                keep.append(flat)
+                kind[i + n * j] = 2
+                ptrs[i + n * j] = flat.ctypes.data
+        h = C.c_void_p()
+        cl = (C.c_int32 * n)(*self.chil)
+        cr = (C.c_int32 * n)(*self.chir)
+        check(be.lib.mpsk_mposlice_create(be.ctx, 0, n, cl, cr, self.d, kind, scal, ptrs, C.byref(h)),
+              "mpsk_mposlice_create")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle and self.be.ctx:
+                self.be.lib.mpsk_mposlice_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+    # host-side helpers mirroring sparseslice.jl:74-106
+    def keys(self):
+        return sorted(self.blocks.keys(), key=lambda t: (t[1], t[0]))
+
+    def contains(self, i, j):
+        return (i, j) in self.blocks and not (np.isscalar(self.blocks[(i, j)]) and self.blocks[(i, j)] == 0)
+
+    def isscal(self, i, j):
+        return self.contains(i, j) and np.isscalar(self.blocks[(i, j)])
+
+
+_default = {}
+
+
+def default_backend(device=None):
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _default:
+        _default[device] = Backend(device)
+    return _default[device]

@@ -1,0 +1,542 @@
+// C ABI of libmpsk (see include/mpsk.h): argument checking, workspace management and the
+// decomposition of every hot-path operator into  MFMA-GEMM -> slab-mix -> MFMA-GEMM  launches.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+#include "mpsk.h"
+#include "mpsk_internal.h"
+
+using namespace mpsk;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(MPSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+#define REQUIRE(cond, msg)                                                  \
+  do {                                                                      \
+    if (!(cond)) return fail(MPSK_ERR_INVALID, std::string(__func__) + ": " + (msg)); \
+  } while (0)
+
+struct mpsk_mposlice {
+  mpsk_ctx* ctx;
+  int Wl, Wr, d;
+  std::vector<double> Ofull;  // [Wl, d, d, Wr] column-major, index (w,t,s,v)
+  MixPlan fwd;                // (w,s) -> (v,t)   in = s + d*w, out = t + d*v
+  MixPlan bwd;                // (v,t) -> (w,s)   in = t + d*v, out = s + d*w
+  std::vector<char> row_used, col_used;
+  double O(int w, int t, int s, int v) const { return Ofull[w + (size_t)Wl * (t + d * (s + (size_t)d * v))]; }
+};
+
+struct mpsk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  double* d_scal = nullptr;     // [MAXK] device scalars
+  double* d_partial = nullptr;  // dot scratch
+  double* h_scal = nullptr;     // pinned host mirror
+  std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
+};
+constexpr int MAXK = 256;
+
+extern "C" {
+
+int mpsk_version(void) { return 100; }
+const char* mpsk_last_error(void) { return g_err.c_str(); }
+
+int mpsk_ctx_create(int device, mpsk_ctx** out) {
+  REQUIRE(out != nullptr, "out is NULL");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  REQUIRE(device >= 0 && device < ndev, "no such HIP device (is a GPU visible?)");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MPSK_ERR_UNSUPPORTED, std::string("libmpsk is built for gfx950 only, device is ") + prop.gcnArchName);
+  mpsk_ctx* c = new mpsk_ctx();
+  c->device = device;
+  HIPCHK(hipMalloc(&c->d_scal, sizeof(double) * MAXK));
+  HIPCHK(hipMalloc(&c->d_partial, sizeof(double) * MPSK_DOT_SCRATCH));
+  HIPCHK(hipHostMalloc(&c->h_scal, sizeof(double) * MAXK, hipHostMallocDefault));
+  *out = c;
+  return MPSK_OK;
+}
+
+int mpsk_ctx_destroy(mpsk_ctx* c) {
+  if (!c) return MPSK_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->pair_plans) mix_plan_destroy(&kv.second);
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->d_scal) (void)hipFree(c->d_scal);
+  if (c->d_partial) (void)hipFree(c->d_partial);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  delete c;
+  return MPSK_OK;
+}
+
+int mpsk_ctx_set_stream(mpsk_ctx* c, void* s) {
+  REQUIRE(c, "ctx is NULL");
+  c->stream = (hipStream_t)s;
+  return MPSK_OK;
+}
+
+int mpsk_ctx_synchronize(mpsk_ctx* c) {
+  REQUIRE(c, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MPSK_OK;
+}
+
+int mpsk_ctx_workspace_reserve(mpsk_ctx* c, size_t bytes) {
+  REQUIRE(c, "ctx is NULL");
+  if (bytes <= c->ws_bytes) return MPSK_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->ws) HIPCHK(hipFree(c->ws));
+  c->ws = nullptr; c->ws_bytes = 0;
+  size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  hipError_t e = hipMalloc(&c->ws, want);
+  if (e != hipSuccess) return fail(MPSK_ERR_NOMEM, "workspace hipMalloc failed");
+  c->ws_bytes = want;
+  return MPSK_OK;
+}
+
+int mpsk_ctx_force_tile(mpsk_ctx* c, int bm, int bn) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE((bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)), "tile must be 64/128");
+  gemm_force_tile(bm, bn);
+  return MPSK_OK;
+}
+
+int mpsk_malloc(mpsk_ctx* c, size_t bytes, void** dptr) {
+  REQUIRE(c && dptr, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+  if (e != hipSuccess) return fail(MPSK_ERR_NOMEM, "hipMalloc failed");
+  return MPSK_OK;
+}
+int mpsk_free(mpsk_ctx* c, void* dptr) {
+  REQUIRE(c, "ctx is NULL");
+  if (dptr) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(dptr)); }
+  return MPSK_OK;
+}
+int mpsk_memcpy_h2d(mpsk_ctx* c, void* dst, const void* src, size_t bytes) {
+  REQUIRE(c, "ctx is NULL");
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MPSK_OK;
+}
+int mpsk_memcpy_d2h(mpsk_ctx* c, void* dst, const void* src, size_t bytes) {
+  REQUIRE(c, "ctx is NULL");
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MPSK_OK;
+}
+int mpsk_memcpy_d2d(mpsk_ctx* c, void* dst, const void* src, size_t bytes) {
+  REQUIRE(c, "ctx is NULL");
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return MPSK_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// MPO slices
+// --------------------------------------------------------------------------------------------
+int mpsk_mposlice_create(mpsk_ctx* c, int dtype, int odim, const int32_t* chi_l, const int32_t* chi_r,
+                         int d, const int32_t* kind, const double* scalars, const void* const* blocks,
+                         mpsk_mposlice** out) {
+  REQUIRE(c && out && chi_l && chi_r && kind, "NULL argument");
+  if (dtype != MPSK_F64) return fail(MPSK_ERR_UNSUPPORTED, "only MPSK_F64 is implemented");
+  REQUIRE(odim > 0 && d > 0, "odim and d must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<int> offl(odim + 1, 0), offr(odim + 1, 0);
+  for (int i = 0; i < odim; ++i) {
+    REQUIRE(chi_l[i] > 0 && chi_r[i] > 0, "chi must be positive");
+    offl[i + 1] = offl[i] + chi_l[i];
+    offr[i + 1] = offr[i] + chi_r[i];
+  }
+  auto* s = new mpsk_mposlice();
+  s->ctx = c; s->Wl = offl[odim]; s->Wr = offr[odim]; s->d = d;
+  s->Ofull.assign((size_t)s->Wl * d * d * s->Wr, 0.0);
+  auto at = [&](int w, int t, int si, int v) -> double& {
+    return s->Ofull[w + (size_t)s->Wl * (t + d * (si + (size_t)d * v))];
+  };
+  for (int j = 0; j < odim; ++j)
+    for (int i = 0; i < odim; ++i) {
+      int k = kind[i + odim * j];
+      if (k == MPSK_BLOCK_ZERO) continue;
+      if (k == MPSK_BLOCK_SCALAR) {
+        if (!scalars || chi_l[i] != chi_r[j]) { delete s; return fail(MPSK_ERR_INVALID, "scalar block needs scalars[] and chi_l[i] == chi_r[j]"); }
+        double cv = scalars[i + odim * j];
+        for (int a = 0; a < chi_l[i]; ++a)
+          for (int t = 0; t < d; ++t) at(offl[i] + a, t, t, offr[j] + a) = cv;
+      } else if (k == MPSK_BLOCK_DENSE) {
+        if (!blocks || !blocks[i + odim * j]) { delete s; return fail(MPSK_ERR_INVALID, "dense block pointer is NULL"); }
+        const double* b = (const double*)blocks[i + odim * j];
+        const int cl = chi_l[i], cr = chi_r[j];
+        for (int v = 0; v < cr; ++v)
+          for (int si = 0; si < d; ++si)
+            for (int t = 0; t < d; ++t)
+              for (int w = 0; w < cl; ++w)
+                at(offl[i] + w, t, si, offr[j] + v) = b[w + (size_t)cl * (t + d * (si + (size_t)d * v))];
+      } else { delete s; return fail(MPSK_ERR_INVALID, "bad block kind"); }
+    }
+  std::vector<MixTerm> fwd, bwd;
+  s->row_used.assign(s->Wl, 0); s->col_used.assign(s->Wr, 0);
+  for (int v = 0; v < s->Wr; ++v)
+    for (int si = 0; si < d; ++si)
+      for (int t = 0; t < d; ++t)
+        for (int w = 0; w < s->Wl; ++w) {
+          double cv = s->O(w, t, si, v);
+          if (cv == 0.0) continue;
+          fwd.push_back({t + d * v, si + d * w, cv});
+          bwd.push_back({si + d * w, t + d * v, cv});
+          s->row_used[w] = 1; s->col_used[v] = 1;
+        }
+  HIPCHK(mix_plan_create(fwd, d * s->Wr, d * s->Wl, &s->fwd));
+  HIPCHK(mix_plan_create(bwd, d * s->Wl, d * s->Wr, &s->bwd));
+  *out = s;
+  return MPSK_OK;
+}
+
+int mpsk_mposlice_destroy(mpsk_mposlice* s) {
+  if (!s) return MPSK_OK;
+  mpsk_ctx* c = s->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto it = c->pair_plans.begin(); it != c->pair_plans.end();) {
+    if (it->first.first == s || it->first.second == s) { mix_plan_destroy(&it->second); it = c->pair_plans.erase(it); }
+    else ++it;
+  }
+  mix_plan_destroy(&s->fwd);
+  mix_plan_destroy(&s->bwd);
+  delete s;
+  return MPSK_OK;
+}
+
+int mpsk_mposlice_dims(const mpsk_mposlice* s, int* Wl, int* Wr, int* d) {
+  REQUIRE(s, "slice is NULL");
+  if (Wl) *Wl = s->Wl;
+  if (Wr) *Wr = s->Wr;
+  if (d) *d = s->d;
+  return MPSK_OK;
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------------
+// helpers
+// --------------------------------------------------------------------------------------------
+static int ensure_ws(mpsk_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return MPSK_OK;
+  return mpsk_ctx_workspace_reserve(c, bytes + bytes / 4);
+}
+
+static GemmArgs mk(const double* A, const double* B, double* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                   int64_t ldc, int tA = 0, int tB = 0) {
+  GemmArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.batch = 1; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = tA; g.transB = tB;
+  return g;
+}
+
+// run a GEMM whose K dimension is a list of segments longer than MAXSEG by chunking (beta = 1)
+static hipError_t gemm_segments(GemmArgs g, const std::vector<int64_t>& sa, const std::vector<int64_t>& sb,
+                                hipStream_t s) {
+  size_t n = sa.size();
+  if (n == 0) return hipErrorInvalidValue;
+  double beta0 = g.beta;
+  for (size_t i0 = 0; i0 < n; i0 += MAXSEG) {
+    int ns = (int)std::min<size_t>(MAXSEG, n - i0);
+    g.nseg = ns;
+    for (int i = 0; i < ns; ++i) { g.segA[i] = sa[i0 + i]; g.segB[i] = sb[i0 + i]; }
+    g.beta = (i0 == 0) ? beta0 : 1.0;
+    hipError_t e = gemm_f64(g, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
+
+extern "C" {
+
+// --------------------------------------------------------------------------------------------
+// derivatives
+// --------------------------------------------------------------------------------------------
+int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
+             const void* x, void* y) {
+  REQUIRE(c && H && GL && GR && x && y, "NULL argument");
+  REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  const int d = H->d, Wl = H->Wl, Wr = H->Wr;
+  const size_t slab = (size_t)Dlo * d * Dr;
+  if (int rc = ensure_ws(c, sizeof(double) * slab * (Wl + Wr))) return rc;
+  double* T1 = (double*)c->ws;
+  double* T2 = T1 + slab * Wl;
+  // stage 1: T1[w] = GL[w] * x     (batched over w)
+  GemmArgs g1 = mk((const double*)GL, (const double*)x, T1, Dlo, d * Dr, Dl, Dlo, Dl, Dlo);
+  g1.batch = Wl; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  HIPCHK(gemm_f64(g1, c->stream));
+  // stage 2: T2[v][:,t,:] = sum_{w,s} O[w,t,s,v] T1[w][:,s,:]
+  SlabIndex ix{d, 1 << 30, (int64_t)Dlo, (int64_t)slab, 0, (int64_t)Dlo * d};
+  HIPCHK(mix_apply(H->fwd, T1, ix, T2, ix, Dlo, Dr, c->stream));
+  // stage 3: y = sum_v T2[v] * GR[v]   (K-segments over v)
+  std::vector<int64_t> sa, sb;
+  for (int v = 0; v < Wr; ++v) if (H->col_used[v]) { sa.push_back((int64_t)v * slab); sb.push_back((int64_t)v * Dr * Dr); }
+  if (sa.empty()) { HIPCHK(zero_async(y, sizeof(double) * slab, c->stream)); return MPSK_OK; }
+  GemmArgs g3 = mk(T2, (const double*)GR, (double*)y, Dlo * d, Dr, Dr, (int64_t)Dlo * d, Dr, (int64_t)Dlo * d);
+  HIPCHK(gemm_segments(g3, sa, sb, c->stream));
+  return MPSK_OK;
+}
+
+int mpsk_dC(mpsk_ctx* c, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR, const void* cm, void* y) {
+  REQUIRE(c && GL && GR && cm && y, "NULL argument");
+  REQUIRE(W > 0 && Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t slab = (size_t)Dlo * Dr;
+  if (int rc = ensure_ws(c, sizeof(double) * slab * W)) return rc;
+  double* T1 = (double*)c->ws;
+  GemmArgs g1 = mk((const double*)GL, (const double*)cm, T1, Dlo, Dr, Dl, Dlo, Dl, Dlo);
+  g1.batch = W; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  HIPCHK(gemm_f64(g1, c->stream));
+  std::vector<int64_t> sa, sb;
+  for (int w = 0; w < W; ++w) { sa.push_back((int64_t)w * slab); sb.push_back((int64_t)w * Dr * Dr); }
+  GemmArgs g3 = mk(T1, (const double*)GR, (double*)y, Dlo, Dr, Dr, Dlo, Dr, Dlo);
+  HIPCHK(gemm_segments(g3, sa, sb, c->stream));
+  return MPSK_OK;
+}
+
+static int pair_plan(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* H2, const MixPlan** out) {
+  auto key = std::make_pair(H1, H2);
+  auto it = c->pair_plans.find(key);
+  if (it != c->pair_plans.end()) { *out = &it->second; return MPSK_OK; }
+  const int d1 = H1->d, d2 = H2->d, Wl = H1->Wl, Wm = H1->Wr, Wr = H2->Wr;
+  // O12[(t1,t2,v) <- (s1,s2,w)] = sum_u O1[w,t1,s1,u] O2[u,t2,s2,v]   (derivatives.jl:128-147)
+  std::map<std::pair<int, int>, double> acc;
+  for (int u = 0; u < Wm; ++u)
+    for (int w = 0; w < Wl; ++w)
+      for (int t1 = 0; t1 < d1; ++t1)
+        for (int s1 = 0; s1 < d1; ++s1) {
+          double a = H1->O(w, t1, s1, u);
+          if (a == 0.0) continue;
+          for (int v = 0; v < Wr; ++v)
+            for (int t2 = 0; t2 < d2; ++t2)
+              for (int s2 = 0; s2 < d2; ++s2) {
+                double b = H2->O(u, t2, s2, v);
+                if (b == 0.0) continue;
+                int o = t1 + d1 * (t2 + d2 * v), in = s1 + d1 * (s2 + d2 * w);
+                acc[{o, in}] += a * b;
+              }
+        }
+  std::vector<MixTerm> terms;
+  for (auto& kv : acc) if (kv.second != 0.0) terms.push_back({kv.first.first, kv.first.second, kv.second});
+  MixPlan p;
+  HIPCHK(mix_plan_create(terms, d1 * d2 * Wr, d1 * d2 * Wl, &p));
+  auto res = c->pair_plans.emplace(key, p);
+  *out = &res.first->second;
+  return MPSK_OK;
+}
+
+int mpsk_dAC2(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* H2, int Dlo, int Dl, int Dr,
+              const void* GL, const void* GR, const void* x2, void* y2) {
+  REQUIRE(c && H1 && H2 && GL && GR && x2 && y2, "NULL argument");
+  REQUIRE(H1->Wr == H2->Wl, "MPO bond dimensions of the two slices do not match");
+  REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  const int d1 = H1->d, d2 = H2->d, Wl = H1->Wl, Wr = H2->Wr;
+  const size_t plane = (size_t)Dlo * d1 * Dr;      // one s2-plane
+  const size_t slab = plane * d2;                  // one w
+  if (int rc = ensure_ws(c, sizeof(double) * slab * (Wl + Wr))) return rc;
+  double* T1 = (double*)c->ws;
+  double* T2 = T1 + slab * Wl;
+  const MixPlan* plan = nullptr;
+  if (int rc = pair_plan(c, H1, H2, &plan)) return rc;
+  GemmArgs g1 = mk((const double*)GL, (const double*)x2, T1, Dlo, d1 * Dr * d2, Dl, Dlo, Dl, Dlo);
+  g1.batch = Wl; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  HIPCHK(gemm_f64(g1, c->stream));
+  SlabIndex ix{d1, d2, (int64_t)Dlo, (int64_t)plane, (int64_t)slab, (int64_t)Dlo * d1};
+  HIPCHK(mix_apply(*plan, T1, ix, T2, ix, Dlo, Dr, c->stream));
+  std::vector<int64_t> sa, sb;
+  for (int v = 0; v < Wr; ++v) if (H2->col_used[v]) { sa.push_back((int64_t)v * slab); sb.push_back((int64_t)v * Dr * Dr); }
+  if (sa.empty()) { HIPCHK(zero_async(y2, sizeof(double) * slab, c->stream)); return MPSK_OK; }
+  GemmArgs g3 = mk(T2, (const double*)GR, (double*)y2, Dlo * d1, Dr, Dr, (int64_t)Dlo * d1, Dr, (int64_t)Dlo * d1);
+  g3.batch = d2; g3.bsA = (int64_t)plane; g3.bsB = 0; g3.bsC = (int64_t)plane;
+  HIPCHK(gemm_segments(g3, sa, sb, c->stream));
+  return MPSK_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// transfers
+// --------------------------------------------------------------------------------------------
+int mpsk_transfer_left(mpsk_ctx* c, const mpsk_mposlice* H, int W, int d, int Dl, int Dr, int Dlb, int Drb,
+                       const void* GLin, const void* A, const void* Ab, void* GLout) {
+  REQUIRE(c && GLin && A && Ab && GLout, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  int Wl = W, Wr = W;
+  if (H) { Wl = H->Wl; Wr = H->Wr; d = H->d; }
+  REQUIRE(Wl > 0 && d > 0 && Dl > 0 && Dr > 0 && Dlb > 0 && Drb > 0, "dimensions must be positive");
+  const size_t slab = (size_t)Dlb * d * Dr;
+  if (int rc = ensure_ws(c, sizeof(double) * slab * (Wl + (H ? Wr : 0)))) return rc;
+  double* T1 = (double*)c->ws;
+  double* T2 = H ? T1 + slab * Wl : T1;
+  // T1[w][p,s,b] = sum_a GLin[w][p,a] A[a,s,b]
+  GemmArgs g1 = mk((const double*)GLin, (const double*)A, T1, Dlb, d * Dr, Dl, Dlb, Dl, Dlb);
+  g1.batch = Wl; g1.bsA = (int64_t)Dlb * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  HIPCHK(gemm_f64(g1, c->stream));
+  if (H) {
+    SlabIndex ix{d, 1 << 30, (int64_t)Dlb, (int64_t)slab, 0, (int64_t)Dlb * d};
+    HIPCHK(mix_apply(H->fwd, T1, ix, T2, ix, Dlb, Dr, c->stream));
+  }
+  // GLout[v][q,b] = sum_{(p,t)} Ab[(p,t),q] T2[v][(p,t),b]
+  GemmArgs g3 = mk((const double*)Ab, T2, (double*)GLout, Drb, Dr, Dlb * d, (int64_t)Dlb * d, (int64_t)Dlb * d, Drb, 1, 0);
+  g3.batch = Wr; g3.bsA = 0; g3.bsB = (int64_t)slab; g3.bsC = (int64_t)Drb * Dr;
+  HIPCHK(gemm_f64(g3, c->stream));
+  return MPSK_OK;
+}
+
+int mpsk_transfer_right(mpsk_ctx* c, const mpsk_mposlice* H, int W, int d, int Dl, int Dr, int Dlb, int Drb,
+                        const void* A, const void* Ab, const void* GRin, void* GRout) {
+  REQUIRE(c && GRin && A && Ab && GRout, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  int Wl = W, Wr = W;
+  if (H) { Wl = H->Wl; Wr = H->Wr; d = H->d; }
+  REQUIRE(Wl > 0 && d > 0 && Dl > 0 && Dr > 0 && Dlb > 0 && Drb > 0, "dimensions must be positive");
+  const size_t plane = (size_t)Dr * Dlb;   // one physical index
+  const size_t slab = plane * d;
+  if (int rc = ensure_ws(c, sizeof(double) * slab * (Wr + (H ? Wl : 0)))) return rc;
+  double* U = (double*)c->ws;
+  double* V = H ? U + slab * Wr : U;
+  // U[v][b,p,t] = sum_q GRin[v][b,q] Ab[(p,t),q]
+  GemmArgs g1 = mk((const double*)GRin, (const double*)Ab, U, Dr, Dlb * d, Drb, Dr, (int64_t)Dlb * d, Dr, 0, 1);
+  g1.batch = Wr; g1.bsA = (int64_t)Dr * Drb; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  HIPCHK(gemm_f64(g1, c->stream));
+  if (H) {
+    SlabIndex ix{d, 1 << 30, (int64_t)plane, (int64_t)slab, 0, (int64_t)Dr};
+    HIPCHK(mix_apply(H->bwd, U, ix, V, ix, Dr, Dlb, c->stream));
+  }
+  // GRout[w][a,p] = sum_s sum_b A[a,s,b] V[w][s][b,p]
+  std::vector<int64_t> sa, sb;
+  for (int s = 0; s < d; ++s) { sa.push_back((int64_t)s * Dl); sb.push_back((int64_t)s * plane); }
+  GemmArgs g3 = mk((const double*)A, V, (double*)GRout, Dl, Dlb, Dr, (int64_t)Dl * d, Dr, Dl);
+  g3.batch = Wl; g3.bsA = 0; g3.bsB = (int64_t)slab; g3.bsC = (int64_t)Dl * Dlb;
+  HIPCHK(gemm_segments(g3, sa, sb, c->stream));
+  return MPSK_OK;
+}
+
+int mpsk_regularize(mpsk_ctx* c, int W, int D1, int D2, void* v, const void* lvec, const void* rvec) {
+  REQUIRE(c && v && lvec && rvec, "NULL argument");
+  REQUIRE(W > 0 && D1 > 0 && D2 > 0, "dimensions must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(regularize(W, D1, D2, (double*)v, (const double*)lvec, (const double*)rvec, c->stream));
+  return MPSK_OK;
+}
+
+int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
+  return fail(MPSK_ERR_UNSUPPORTED, "mpsk_qrpos: not implemented yet");
+}
+int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq) {
+  return fail(MPSK_ERR_UNSUPPORTED, "mpsk_lqpos: not implemented yet");
+}
+int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, int ldu, void* S, void* Vh,
+              int ldv, int max_keep, double trunc_err, int* kept, double* disc_norm) {
+  return fail(MPSK_ERR_UNSUPPORTED, "mpsk_tsvd: not implemented yet");
+}
+
+int mpsk_gemm(mpsk_ctx* c, int transA, int transB, int M, int N, int K, double alpha, const void* A, int64_t lda,
+              const void* B, int64_t ldb, double beta, void* C, int64_t ldc) {
+  REQUIRE(c && A && B && C, "NULL argument");
+  REQUIRE(M > 0 && N > 0 && K > 0, "dimensions must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  GemmArgs g = mk((const double*)A, (const double*)B, (double*)C, M, N, K, lda, ldb, ldc, transA ? 1 : 0, transB ? 1 : 0);
+  g.alpha = alpha; g.beta = beta;
+  HIPCHK(gemm_f64(g, c->stream));
+  return MPSK_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// vectors
+// --------------------------------------------------------------------------------------------
+static int fetch_scalars(mpsk_ctx* c, int k, double* host_out) {
+  HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::memcpy(host_out, c->h_scal, sizeof(double) * k);
+  return MPSK_OK;
+}
+
+int mpsk_vmultidot(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const void* y, double* host_out) {
+  REQUIRE(c && xs && y && host_out, "NULL argument");
+  REQUIRE(k > 0 && k <= MAXK && n > 0, "bad k or n");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(vec_multidot((const double* const*)xs, k, (const double*)y, n, c->d_scal, c->d_partial, c->stream));
+  return fetch_scalars(c, k, host_out);
+}
+
+int mpsk_vdot(mpsk_ctx* c, int64_t n, const void* x, const void* y, double* host_out) {
+  const void* xs[1] = {x};
+  return mpsk_vmultidot(c, n, 1, xs, y, host_out);
+}
+
+int mpsk_vnrm2(mpsk_ctx* c, int64_t n, const void* x, double* host_out) {
+  double v = 0.0;
+  if (int rc = mpsk_vdot(c, n, x, x, &v)) return rc;
+  *host_out = std::sqrt(v);
+  return MPSK_OK;
+}
+
+int mpsk_vgs_step(mpsk_ctx* c, int64_t n, int k, const void* const* xs, void* y, double* host_out) {
+  REQUIRE(c && xs && y && host_out, "NULL argument");
+  REQUIRE(k > 0 && k <= MAXK && n > 0, "bad k or n");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(vec_multidot((const double* const*)xs, k, (const double*)y, n, c->d_scal, c->d_partial, c->stream));
+  HIPCHK(vec_multiaxpy((const double* const*)xs, c->d_scal, k, -1.0, (double*)y, n, c->stream));
+  return fetch_scalars(c, k, host_out);
+}
+
+int mpsk_vlincomb(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y) {
+  REQUIRE(c && xs && y && host_coefs, "NULL argument");
+  REQUIRE(k > 0 && k <= MAXK && n > 0, "bad k or n");
+  HIPCHK(hipSetDevice(c->device));
+  // coefficients travel through the pinned mirror; sync first so a previous fetch is not clobbered
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::memcpy(c->h_scal, host_coefs, sizeof(double) * k);
+  HIPCHK(hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(y, 0, sizeof(double) * n, c->stream));
+  HIPCHK(vec_multiaxpy((const double* const*)xs, c->d_scal, k, 1.0, (double*)y, n, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MPSK_OK;
+}
+
+int mpsk_vaxpby(mpsk_ctx* c, int64_t n, double alpha, const void* x, double beta, void* y) {
+  REQUIRE(c && x && y, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(vec_axpby(alpha, (const double*)x, beta, (double*)y, n, c->stream));
+  return MPSK_OK;
+}
+int mpsk_vscal(mpsk_ctx* c, int64_t n, double alpha, void* x) {
+  REQUIRE(c && x, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(vec_scal(alpha, (double*)x, n, c->stream));
+  return MPSK_OK;
+}
+int mpsk_vcopy(mpsk_ctx* c, int64_t n, const void* x, void* y) {
+  REQUIRE(c && x && y, "NULL argument");
+  HIPCHK(hipMemcpyAsync(y, x, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  return MPSK_OK;
+}
+int mpsk_vzero(mpsk_ctx* c, int64_t n, void* x) {
+  REQUIRE(c && x, "NULL argument");
+  HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * n, c->stream));
+  return MPSK_OK;
+}
+
+}  // extern "C"

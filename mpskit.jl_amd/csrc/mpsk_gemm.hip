@@ -1,0 +1,257 @@
+// fp64 MFMA GEMM core for gfx950 (MI355X) -- the contraction engine behind every hot-path op
+// (dAC / dC / dAC2 / transfer_left / transfer_right / gauge products).
+//
+//   C_z[m,n] = alpha * sum_seg sum_k opA(A_z,seg)[m,k] * opB(B_z,seg)[k,n] + beta * C_z[m,n]
+//
+// * all matrices column-major (TensorKit / Fortran order), z = batch index (blockIdx.y),
+//   "seg" = K-segments with independent base offsets: this is how the sum over MPO levels
+//   (derivatives.jl:85-89, transfer.jl:188-207 in the reference) becomes ONE launch.
+// * v_mfma_f64_16x16x4_f64, 4 waves (2x2) per workgroup, LDS double-buffered with register
+//   prefetch of the next K-tile; the MFMA operands are swapped (n-side fragment as MFMA-A) so
+//   that a lane's accumulator column index (lane&15) is the memory-contiguous m index and the
+//   epilogue writes full 128-B lines.
+// * LDS images are padded so that ds_read_b64 fragment reads are bank-conflict free:
+//     MN-major image [BK][BMN+16]   (k-row stride == 128 B mod 256 B)
+//     K-major  image [BMN][BK+2]    (row stride 144 B: 16 rows hit 16 distinct 16-B slots)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mpsk_internal.h"
+
+namespace mpsk {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+template <int BMN, bool KMAJOR> struct LdsImg {
+  static constexpr int STRIDE = KMAJOR ? (BK + 2) : (BMN + 16);
+  static constexpr int SIZE = KMAJOR ? BMN * (BK + 2) : BK * (BMN + 16);  // doubles
+  __device__ static inline int idx(int mn, int k) { return KMAJOR ? mn * STRIDE + k : k * STRIDE + mn; }
+};
+
+// Loader for one operand tile (BMN x BK).  KCONTIG: element (mn,k) at base[k + mn*ld], else
+// base[mn + k*ld].  The LDS image is K-major iff KCONTIG, so global reads and LDS writes are both
+// 16-B vectors along the contiguous direction.
+template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
+  static constexpr int NV = BMN * BK / 2 / NTHREADS;  // 16-B vectors per thread
+  using Img = LdsImg<BMN, KCONTIG>;
+  d2 r[NV];
+
+  __device__ inline void load(const double* __restrict__ base, int64_t ld, int mn0, int k0,
+                              int MN, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int v = tid + i * NTHREADS;
+      int mn, k;
+      if (KCONTIG) { k = (v % (BK / 2)) * 2; mn = v / (BK / 2); }
+      else         { mn = (v % (BMN / 2)) * 2; k = v / (BMN / 2); }
+      int gmn = mn0 + mn, gk = k0 + k;
+      if (ALIGNED) {
+        const double* p = KCONTIG ? base + gk + (int64_t)gmn * ld : base + gmn + (int64_t)gk * ld;
+        r[i] = *reinterpret_cast<const d2*>(p);
+      } else {
+        d2 t = {0.0, 0.0};
+        if (KCONTIG) {
+          if (gmn < MN) {
+            const double* p = base + gk + (int64_t)gmn * ld;
+            if (gk < K) t.x = p[0];
+            if (gk + 1 < K) t.y = p[1];
+          }
+        } else {
+          if (gk < K) {
+            const double* p = base + gmn + (int64_t)gk * ld;
+            if (gmn < MN) t.x = p[0];
+            if (gmn + 1 < MN) t.y = p[1];
+          }
+        }
+        r[i] = t;
+      }
+    }
+  }
+  __device__ inline void store(double* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int v = tid + i * NTHREADS;
+      int mn, k;
+      if (KCONTIG) { k = (v % (BK / 2)) * 2; mn = v / (BK / 2); }
+      else         { mn = (v % (BMN / 2)) * 2; k = v / (BMN / 2); }
+      *reinterpret_cast<d2*>(&lds[Img::idx(mn, k)]) = r[i];
+    }
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile (2x2 waves)
+  constexpr int TM = WTM / 16, TN = WTN / 16; // MFMA tiles per wave
+  // A is "k-contiguous" when transposed, B is "k-contiguous" when NOT transposed
+  using LA = TileLoader<BM, TA, ALIGNED>;
+  using LB = TileLoader<BN, !TB, ALIGNED>;
+  using IA = typename LA::Img;
+  using IB = typename LB::Img;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const sA = smem;                  // two A images, then two B images
+  double* const sB = smem + 2 * IA::SIZE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // XCD-aware tile mapping: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
+  // chunk of the tile list so neighbouring tiles (sharing an A row panel) hit the same L2.
+  const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+  const int ntiles = tilesM * tilesN;
+  int bid = blockIdx.x;
+  {
+    int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, pos = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int bm = bid % tilesM, bn = bid / tilesM;
+  const int z = blockIdx.y;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const double* Ab = g.A + (int64_t)z * g.bsA;
+  const double* Bb = g.B + (int64_t)z * g.bsB;
+  double* Cb = g.C + (int64_t)z * g.bsC;
+
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  const int tps = (g.K + BK - 1) / BK;  // k-tiles per segment
+  const int nt = tps * g.nseg;
+  LA la; LB lb;
+
+  la.load(Ab + g.segA[0], g.lda, m0, 0, g.M, g.K, tid);
+  lb.load(Bb + g.segB[0], g.ldb, n0, 0, g.N, g.K, tid);
+  la.store(sA, tid);
+  lb.store(sB, tid);
+  __syncthreads();
+
+  int seg = 0, kt = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    int kt2 = kt + 1, seg2 = seg;
+    if (kt2 == tps) { kt2 = 0; seg2 = seg + 1; }
+    if (t + 1 < nt) {
+      la.load(Ab + g.segA[seg2], g.lda, m0, kt2 * BK, g.M, g.K, tid);
+      lb.load(Bb + g.segB[seg2], g.ldb, n0, kt2 * BK, g.N, g.K, tid);
+    }
+    const double* a_s = sA + cur * IA::SIZE;
+    const double* b_s = sB + cur * IB::SIZE;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      double af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = a_s[IA::idx(wm * WTM + i * 16 + fr, ks + fq)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = b_s[IB::idx(wn * WTN + j * 16 + fr, ks + fq)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      la.store(sA + (cur ^ 1) * IA::SIZE, tid);
+      lb.store(sB + (cur ^ 1) * IB::SIZE, tid);
+    }
+    __syncthreads();
+    kt = kt2; seg = seg2;
+  }
+
+  // epilogue: lane holds C[m = .. + fr][n = .. + fq + 4*reg]
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = n0 + wn * WTN + j * 16 + fq + 4 * rg;
+        if (ALIGNED || (m < g.M && n < g.N)) {
+          double* p = Cb + m + (int64_t)n * g.ldc;
+          double v = alpha * acc[i][j][rg];
+          if (beta != 0.0) v += beta * (*p);
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
+  using LA = TileLoader<BM, TA, ALIGNED>;
+  using LB = TileLoader<BN, !TB, ALIGNED>;
+  constexpr size_t smem = (2 * LA::Img::SIZE + 2 * LB::Img::SIZE) * sizeof(double);
+  auto kern = gemm_f64_kernel<BM, BN, TA, TB, ALIGNED>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+  dim3 grid(tilesM * tilesN, g.batch, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, s, g);
+  return hipGetLastError();
+}
+
+template <bool TA, bool TB, bool ALIGNED>
+static hipError_t launch_tile(const GemmArgs& g, int bm, int bn, hipStream_t s) {
+  if (bm == 128 && bn == 128) return launch_cfg<128, 128, TA, TB, ALIGNED>(g, s);
+  if (bm == 64 && bn == 128) return launch_cfg<64, 128, TA, TB, ALIGNED>(g, s);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, TA, TB, ALIGNED>(g, s);
+  return launch_cfg<64, 64, TA, TB, ALIGNED>(g, s);
+}
+
+// Tile choice: minimise the makespan estimate  ceil(tiles / slots) * tile_cost / efficiency.
+// 256 CUs; every CU runs at most 2 workgroups, each at half the MFMA rate, so the cost of a
+// round is proportional to the tile volume; smaller tiles have lower MFMA density.
+static void choose_tile(int M, int N, int batch, int* bm, int* bn) {
+  const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  const double eff[4] = {1.0, 0.97, 0.97, 0.93};
+  double best = 1e300;
+  for (int c = 0; c < 4; ++c) {
+    int tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
+    double tiles = (double)tm * tn * batch;
+    double rounds = ceil(tiles / 256.0);
+    double cost = rounds * cand[c][0] * cand[c][1] / eff[c];
+    if (cost < best * 0.999) { best = cost; *bm = cand[c][0]; *bn = cand[c][1]; }
+  }
+}
+
+static int g_force_bm = 0, g_force_bn = 0;
+void gemm_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
+
+hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
+  GemmArgs g = g_in;
+  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
+  if (g.K <= 0 || g.nseg <= 0) {  // pure scaling C = beta*C is not needed by any caller
+    return hipErrorInvalidValue;
+  }
+  int bm = 128, bn = 128;
+  choose_tile(g.M, g.N, g.batch, &bm, &bn);
+  if (g_force_bm) { bm = g_force_bm; bn = g_force_bn; }
+  bool aligned = (g.M % bm == 0) && (g.N % bn == 0) && (g.K % BK == 0) && (g.lda % 2 == 0) &&
+                 (g.ldb % 2 == 0) && (g.bsA % 2 == 0) && (g.bsB % 2 == 0) &&
+                 ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
+  for (int i = 0; i < g.nseg; ++i) aligned = aligned && (g.segA[i] % 2 == 0) && (g.segB[i] % 2 == 0);
+#define MPSK_DISPATCH(TA_, TB_)                                                        \
+  return aligned ? launch_tile<TA_, TB_, true>(g, bm, bn, s) : launch_tile<TA_, TB_, false>(g, bm, bn, s)
+  if (!g.transA && !g.transB) { MPSK_DISPATCH(false, false); }
+  if (g.transA && !g.transB) { MPSK_DISPATCH(true, false); }
+  if (!g.transA && g.transB) { MPSK_DISPATCH(false, true); }
+  MPSK_DISPATCH(true, true);
+#undef MPSK_DISPATCH
+}
+
+}  // namespace mpsk

@@ -1,0 +1,67 @@
+// Internal declarations shared by the HIP translation units of libmpsk (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include <string>
+
+namespace mpsk {
+
+constexpr int MAXSEG = 32;
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int M, N, K;               // K = length of ONE segment
+  int64_t lda, ldb, ldc;
+  int64_t bsA, bsB, bsC;     // batch strides (elements)
+  int batch;
+  int nseg;
+  int64_t segA[MAXSEG], segB[MAXSEG];  // element offsets of each K-segment
+  double alpha, beta;
+  int transA, transB;        // 0: col-major as given; 1: operand is the transpose of a col-major matrix
+};
+
+hipError_t gemm_f64(const GemmArgs& g, hipStream_t s);
+void gemm_force_tile(int bm, int bn);
+
+// ---- slab mixing:  out_slab[o][r,c] = sum_t coef[t] * in_slab[src[t]][r,c]  --------------------
+// A "slab" is an R x C column-major matrix view (ld, base offset) inside a larger tensor.  This
+// is the (w,s) -> (v,t) application of the small MPO tensor between the two big GEMMs.
+struct MixTerm { int32_t out, in; double coef; };
+
+struct MixPlan {          // device-resident CSR: terms grouped by output slab
+  int n_out = 0, n_in = 0;
+  int32_t* d_rowptr = nullptr;   // [n_out+1]
+  int32_t* d_src = nullptr;      // [nnz]
+  double* d_coef = nullptr;      // [nnz]
+  int nnz = 0;
+  int max_terms = 0;
+};
+
+hipError_t mix_plan_create(const std::vector<MixTerm>& terms, int n_out, int n_in, MixPlan* plan);
+void mix_plan_destroy(MixPlan* plan);
+
+// slab j = j0 + n0*(j1 + n1*j2) lives at element offset j0*s0 + j1*s1 + j2*s2; rows contiguous,
+// column stride ld.
+struct SlabIndex { int n0, n1; int64_t s0, s1, s2; int64_t ld; };
+hipError_t mix_apply(const MixPlan& plan, const double* in, SlabIndex iin, double* out, SlabIndex iout,
+                     int R, int C, hipStream_t s);
+
+// ---- vector kernels ---------------------------------------------------------------------------
+// xs: HOST array of k device pointers; d_out / d_coefs: device [k]; d_partial: device scratch
+// [MPSK_DOT_SCRATCH doubles].  Vectors must be 16-B aligned.
+constexpr int MPSK_DOT_SCRATCH = 8 * 1024;
+hipError_t vec_multidot(const double* const* xs, int k, const double* y, int64_t n, double* d_out,
+                        double* d_partial, hipStream_t s);
+hipError_t vec_axpby(double a, const double* x, double b, double* y, int64_t n, hipStream_t s);
+hipError_t vec_scal(double a, double* x, int64_t n, hipStream_t s);
+hipError_t vec_multiaxpy(const double* const* xs, const double* d_coefs, int k, double sign, double* y,
+                         int64_t n, hipStream_t s);
+
+// ---- gauge kernels ----------------------------------------------------------------------------
+hipError_t regularize(int W, int D1, int D2, double* v, const double* lvec, const double* rvec, hipStream_t s);
+
+}  // namespace mpsk

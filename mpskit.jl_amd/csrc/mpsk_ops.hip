@@ -1,0 +1,302 @@
+// HBM-bound helper kernels of libmpsk: MPO "slab mixing" between the two MFMA GEMM stages and the
+// Krylov vector kernels (dot / multi-dot / axpby / multi-axpy) with 64-lane wavefront reductions.
+#include <hip/hip_runtime.h>
+#include "mpsk_internal.h"
+
+namespace mpsk {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// -------------------------------------------------------------------------------------------
+// slab mixing
+// -------------------------------------------------------------------------------------------
+__device__ inline int64_t slab_off(const SlabIndex& ix, int j) {
+  int j0 = j % ix.n0;
+  int t = j / ix.n0;
+  int j1 = t % ix.n1;
+  int j2 = t / ix.n1;
+  return j0 * ix.s0 + j1 * ix.s1 + j2 * ix.s2;
+}
+
+template <bool VEC2>
+__global__ __launch_bounds__(256) void mix_kernel(const int32_t* __restrict__ rowptr,
+                                                  const int32_t* __restrict__ src,
+                                                  const double* __restrict__ coef,
+                                                  const double* __restrict__ in, SlabIndex iin,
+                                                  double* __restrict__ out, SlabIndex iout, int R, int C) {
+  const int o = blockIdx.y;
+  const int t0 = rowptr[o], t1 = rowptr[o + 1];
+  double* op = out + slab_off(iout, o);
+  if (VEC2) {
+    const int R2 = R >> 1;
+    const int64_t total = (int64_t)R2 * C;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+      int r = (int)(e % R2) * 2, c = (int)(e / R2);
+      d2 acc = {0.0, 0.0};
+      for (int t = t0; t < t1; ++t) {
+        const double* ip = in + slab_off(iin, src[t]) + r + (int64_t)c * iin.ld;
+        d2 v = *reinterpret_cast<const d2*>(ip);
+        double cf = coef[t];
+        acc.x += cf * v.x;
+        acc.y += cf * v.y;
+      }
+      *reinterpret_cast<d2*>(op + r + (int64_t)c * iout.ld) = acc;
+    }
+  } else {
+    const int64_t total = (int64_t)R * C;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+      int r = (int)(e % R), c = (int)(e / R);
+      double acc = 0.0;
+      for (int t = t0; t < t1; ++t)
+        acc += coef[t] * in[slab_off(iin, src[t]) + r + (int64_t)c * iin.ld];
+      op[r + (int64_t)c * iout.ld] = acc;
+    }
+  }
+}
+
+hipError_t mix_plan_create(const std::vector<MixTerm>& terms, int n_out, int n_in, MixPlan* plan) {
+  std::vector<int32_t> rowptr(n_out + 1, 0), src(terms.size());
+  std::vector<double> coef(terms.size());
+  for (auto& t : terms) rowptr[t.out + 1]++;
+  int mx = 0;
+  for (int i = 0; i < n_out; ++i) { if (rowptr[i + 1] > mx) mx = rowptr[i + 1]; rowptr[i + 1] += rowptr[i]; }
+  std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+  for (auto& t : terms) { int p = fill[t.out]++; src[p] = t.in; coef[p] = t.coef; }
+  plan->n_out = n_out; plan->n_in = n_in; plan->nnz = (int)terms.size(); plan->max_terms = mx;
+  hipError_t e;
+  if ((e = hipMalloc(&plan->d_rowptr, sizeof(int32_t) * (n_out + 1))) != hipSuccess) return e;
+  size_t nz = terms.size() ? terms.size() : 1;
+  if ((e = hipMalloc(&plan->d_src, sizeof(int32_t) * nz)) != hipSuccess) return e;
+  if ((e = hipMalloc(&plan->d_coef, sizeof(double) * nz)) != hipSuccess) return e;
+  if ((e = hipMemcpy(plan->d_rowptr, rowptr.data(), sizeof(int32_t) * (n_out + 1), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if (terms.size()) {
+    if ((e = hipMemcpy(plan->d_src, src.data(), sizeof(int32_t) * terms.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(plan->d_coef, coef.data(), sizeof(double) * terms.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+void mix_plan_destroy(MixPlan* plan) {
+  if (plan->d_rowptr) (void)hipFree(plan->d_rowptr);
+  if (plan->d_src) (void)hipFree(plan->d_src);
+  if (plan->d_coef) (void)hipFree(plan->d_coef);
+  *plan = MixPlan();
+}
+
+hipError_t mix_apply(const MixPlan& plan, const double* in, SlabIndex iin, double* out, SlabIndex iout,
+                     int R, int C, hipStream_t s) {
+  if (R <= 0 || C <= 0 || plan.n_out <= 0) return hipSuccess;
+  bool vec2 = (R % 2 == 0) && (iin.ld % 2 == 0) && (iout.ld % 2 == 0) && (iin.s0 % 2 == 0) &&
+              (iin.s1 % 2 == 0) && (iin.s2 % 2 == 0) && (iout.s0 % 2 == 0) && (iout.s1 % 2 == 0) &&
+              (iout.s2 % 2 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  int64_t work = vec2 ? (int64_t)(R / 2) * C : (int64_t)R * C;
+  int bx = (int)((work + 255) / 256);
+  int cap = (2048 + plan.n_out - 1) / plan.n_out;
+  if (cap < 1) cap = 1;
+  if (bx > cap * 4) bx = cap * 4;
+  if (bx < 1) bx = 1;
+  dim3 grid(bx, plan.n_out, 1);
+  if (vec2)
+    hipLaunchKernelGGL(mix_kernel<true>, grid, dim3(256), 0, s, plan.d_rowptr, plan.d_src, plan.d_coef, in,
+                       iin, out, iout, R, C);
+  else
+    hipLaunchKernelGGL(mix_kernel<false>, grid, dim3(256), 0, s, plan.d_rowptr, plan.d_src, plan.d_coef, in,
+                       iin, out, iout, R, C);
+  return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// vector kernels
+// -------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// block-level sum of NV values per thread; result valid in thread 0
+template <int NV> __device__ inline void block_sum(double (&v)[NV], double* sh /* [4*NV] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double w = wave_sum(v[i]);
+    if (lane == 0) sh[wave * NV + i] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = sh[i] + sh[NV + i] + sh[2 * NV + i] + sh[3 * NV + i];
+  }
+  __syncthreads();
+}
+
+constexpr int DOT_BLOCKS = 1024;
+constexpr int MD = 8;  // vectors per multidot pass
+
+struct PtrPack { const double* p[MD]; };
+
+// partial[j*DOT_BLOCKS + b] = sum over block b's elements of xs[j] . y
+template <int NVEC>
+__global__ __launch_bounds__(256) void multidot_kernel(PtrPack xs, const double* __restrict__ y, int64_t n,
+                                                       double* __restrict__ partial) {
+  __shared__ double sh[4 * NVEC];
+  double acc[NVEC];
+#pragma unroll
+  for (int j = 0; j < NVEC; ++j) acc[j] = 0.0;
+  const int64_t n2 = n >> 1;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) {
+    d2 yv = *reinterpret_cast<const d2*>(y + 2 * e);
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+      d2 xv = *reinterpret_cast<const d2*>(xs.p[j] + 2 * e);
+      acc[j] += xv.x * yv.x + xv.y * yv.y;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) acc[j] += xs.p[j][n - 1] * y[n - 1];
+  }
+  block_sum<NVEC>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) partial[(int64_t)j * DOT_BLOCKS + blockIdx.x] = acc[j];
+  }
+}
+
+// out[j] = sum_b partial[j*DOT_BLOCKS + b]   (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void dot_final_kernel(const double* __restrict__ partial, int nblocks,
+                                                        double* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc[1] = {0.0};
+  const double* p = partial + (int64_t)blockIdx.x * DOT_BLOCKS;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc[0] += p[i];
+  block_sum<1>(acc, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc[0];
+}
+
+static int dot_grid(int64_t n) {
+  int64_t b = (n / 2 + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > DOT_BLOCKS) b = DOT_BLOCKS;
+  return (int)b;
+}
+
+// xs: HOST array of k device pointers.  d_out: device [k].  d_partial: device [MD*DOT_BLOCKS].
+// Requires all vectors 16-B aligned (library allocations are).
+hipError_t vec_multidot(const double* const* xs, int k, const double* y, int64_t n, double* d_out,
+                        double* d_partial, hipStream_t s) {
+  const int nb = dot_grid(n);
+  for (int j0 = 0; j0 < k; j0 += MD) {
+    int nv = k - j0 < MD ? k - j0 : MD;
+    PtrPack pk;
+    for (int j = 0; j < MD; ++j) pk.p[j] = xs[j0 + (j < nv ? j : 0)];
+    switch (nv) {
+      case 1: hipLaunchKernelGGL(multidot_kernel<1>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+      case 2: hipLaunchKernelGGL(multidot_kernel<2>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+      case 3: hipLaunchKernelGGL(multidot_kernel<3>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+      case 4: hipLaunchKernelGGL(multidot_kernel<4>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+      case 5: hipLaunchKernelGGL(multidot_kernel<5>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+      case 6: hipLaunchKernelGGL(multidot_kernel<6>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+      case 7: hipLaunchKernelGGL(multidot_kernel<7>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+      default: hipLaunchKernelGGL(multidot_kernel<8>, dim3(nb), dim3(256), 0, s, pk, y, n, d_partial); break;
+    }
+    hipLaunchKernelGGL(dot_final_kernel, dim3(nv), dim3(256), 0, s, d_partial, nb, d_out + j0);
+  }
+  return hipGetLastError();
+}
+
+// y = a*x + b*y   (b == 0: y is not read, so it may hold NaN / be uninitialised)
+__global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __restrict__ x, double b,
+                                                    double* __restrict__ y, int64_t n) {
+  const int64_t n2 = n >> 1;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) {
+    d2 xv = *reinterpret_cast<const d2*>(x + 2 * e);
+    d2 r;
+    if (b == 0.0) { r.x = a * xv.x; r.y = a * xv.y; }
+    else {
+      d2 yv = *reinterpret_cast<const d2*>(y + 2 * e);
+      r.x = a * xv.x + b * yv.x; r.y = a * xv.y + b * yv.y;
+    }
+    *reinterpret_cast<d2*>(y + 2 * e) = r;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+    y[n - 1] = (b == 0.0) ? a * x[n - 1] : a * x[n - 1] + b * y[n - 1];
+}
+
+__global__ __launch_bounds__(256) void scal_kernel(double a, double* x, int64_t n) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    x[e] *= a;
+}
+
+hipError_t vec_scal(double a, double* x, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(scal_kernel, dim3((int)nb), dim3(256), 0, s, a, x, n);
+  return hipGetLastError();
+}
+
+hipError_t vec_axpby(double a, const double* x, double b, double* y, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  int64_t nb = (n / 2 + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(axpby_kernel, dim3((int)nb), dim3(256), 0, s, a, x, b, y, n);
+  return hipGetLastError();
+}
+
+// y += sign * sum_j coefs[j] * xs[j]    (coefs on device: produced by vec_multidot, no host sync)
+template <int NVEC>
+__global__ __launch_bounds__(256) void multiaxpy_kernel(PtrPack xs, const double* __restrict__ coefs, double sign,
+                                                        double* __restrict__ y, int64_t n) {
+  double c[NVEC];
+#pragma unroll
+  for (int j = 0; j < NVEC; ++j) c[j] = sign * coefs[j];
+  const int64_t n2 = n >> 1;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) {
+    d2 yv = *reinterpret_cast<const d2*>(y + 2 * e);
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+      d2 xv = *reinterpret_cast<const d2*>(xs.p[j] + 2 * e);
+      yv.x += c[j] * xv.x;
+      yv.y += c[j] * xv.y;
+    }
+    *reinterpret_cast<d2*>(y + 2 * e) = yv;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double v = y[n - 1];
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) v += c[j] * xs.p[j][n - 1];
+    y[n - 1] = v;
+  }
+}
+
+hipError_t vec_multiaxpy(const double* const* xs, const double* d_coefs, int k, double sign, double* y,
+                         int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  int64_t nb64 = (n / 2 + 255) / 256;
+  if (nb64 < 1) nb64 = 1;
+  if (nb64 > 4096) nb64 = 4096;
+  const int nb = (int)nb64;
+  for (int j0 = 0; j0 < k; j0 += MD) {
+    int nv = k - j0 < MD ? k - j0 : MD;
+    PtrPack pk;
+    for (int j = 0; j < MD; ++j) pk.p[j] = xs[j0 + (j < nv ? j : 0)];
+    const double* cf = d_coefs + j0;
+    switch (nv) {
+      case 1: hipLaunchKernelGGL(multiaxpy_kernel<1>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+      case 2: hipLaunchKernelGGL(multiaxpy_kernel<2>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+      case 3: hipLaunchKernelGGL(multiaxpy_kernel<3>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+      case 4: hipLaunchKernelGGL(multiaxpy_kernel<4>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+      case 5: hipLaunchKernelGGL(multiaxpy_kernel<5>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+      case 6: hipLaunchKernelGGL(multiaxpy_kernel<6>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+      case 7: hipLaunchKernelGGL(multiaxpy_kernel<7>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+      default: hipLaunchKernelGGL(multiaxpy_kernel<8>, dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n); break;
+    }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mpsk

@@ -1,0 +1,158 @@
+"""GPU parity of the hot-path operators (through the C ABI) against the NumPy oracle.
+
+Tolerance: fp64, |y_gpu - y_oracle| <= 1e-12 * ||y_oracle||_inf-scale (north star: energies to
+1e-10 relative; the operators themselves are held to ~100 ulp of the accumulated magnitude)."""
+import numpy as np
+import pytest
+
+import mpskit_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-13
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def rand_slice(rng, odim, d, chis, density=0.6, scal_prob=0.3):
+    """random block-sparse slice with the MPOHamiltonian structure (upper triangular, 1 on corners)."""
+    blocks = {(0, 0): 1.0, (odim - 1, odim - 1): 1.0}
+    for i in range(odim):
+        for j in range(i, odim):
+            if (i, j) in blocks:
+                continue
+            if rng.random() < density:
+                if chis[i] == chis[j] and rng.random() < scal_prob:
+                    blocks[(i, j)] = float(rng.standard_normal())
+                else:
+                    blocks[(i, j)] = rng.standard_normal((chis[i], d, d, chis[j]))
+    return mo.SparseMPOSlice(odim, d, chis, chis, blocks)
+
+
+def dev_slice(be, s):
+    return be.mposlice(s.odim, s.d, s.chil, s.chir, dict(s.Os))
+
+
+def rand_env(rng, chis, Db, Dk):
+    return [rng.standard_normal((Db, c, Dk)) for c in chis]
+
+
+CASES = [
+    # (Dl, Dr, d, chis)
+    (4, 4, 2, [1, 1, 1]),
+    (16, 16, 2, [1, 1, 1, 1, 1]),
+    (7, 13, 3, [1, 2, 1]),          # ragged, chi > 1
+    (64, 64, 2, [1, 1, 1, 1, 1]),
+    (33, 65, 2, [1, 3, 2, 1]),
+    (128, 128, 4, [1, 1, 1, 1, 1, 1]),
+    (256, 256, 3, [1, 1, 1, 1, 1]),  # config 2 shape
+    (1, 2, 2, [1, 1, 1]),            # chain edge
+]
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", CASES)
+def test_dAC(be, Dl, Dr, d, chis):
+    rng = np.random.default_rng(20240213 + Dl * 7 + Dr)
+    s = rand_slice(rng, len(chis), d, chis)
+    GL, GR = rand_env(rng, chis, Dl, Dl), rand_env(rng, chis, Dr, Dr)
+    x = rng.standard_normal((Dl, d, Dr))
+    ref = mo.dAC(x, s, GL, GR)
+    y = be.download(be.dAC(dev_slice(be, s), be.upload_env(GL), be.upload_env(GR), be.upload(x)))
+    assert relerr(y, ref) < RTOL * max(Dl, Dr)
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", CASES)
+def test_dC(be, Dl, Dr, d, chis):
+    rng = np.random.default_rng(5 + Dl)
+    GL, GR = rand_env(rng, chis, Dl, Dl), rand_env(rng, chis, Dr, Dr)
+    c = rng.standard_normal((Dl, Dr))
+    ref = mo.dC(c, GL, GR)
+    y = be.download(be.dC(be.upload_env(GL), be.upload_env(GR), be.upload(c)))
+    assert relerr(y, ref) < RTOL * max(Dl, Dr)
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", [c for c in CASES if c[0] <= 128])
+def test_dAC2(be, Dl, Dr, d, chis):
+    rng = np.random.default_rng(11 + Dl)
+    s1 = rand_slice(rng, len(chis), d, chis)
+    s2 = rand_slice(rng, len(chis), d, chis)
+    GL, GR = rand_env(rng, chis, Dl, Dl), rand_env(rng, chis, Dr, Dr)
+    x = rng.standard_normal((Dl, d, Dr, d))
+    ref = mo.dAC2(x, s1, s2, GL, GR)
+    y = be.download(be.dAC2(dev_slice(be, s1), dev_slice(be, s2), be.upload_env(GL), be.upload_env(GR),
+                            be.upload(x)))
+    assert relerr(y, ref) < RTOL * max(Dl, Dr) * d
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", CASES)
+def test_transfer_left_right(be, Dl, Dr, d, chis):
+    rng = np.random.default_rng(17 + Dl)
+    s = rand_slice(rng, len(chis), d, chis)
+    ds = dev_slice(be, s)
+    A = rng.standard_normal((Dl, d, Dr))
+    Ab = rng.standard_normal((Dl, d, Dr))
+    GL, GR = rand_env(rng, chis, Dl, Dl), rand_env(rng, chis, Dr, Dr)
+    refL = mo.transfer_left(GL, s, A, Ab)
+    outL = be.download_env(be.transfer_left(ds, be.upload_env(GL), be.upload(A), be.upload(Ab)), chis)
+    for a, b in zip(outL, refL):
+        assert relerr(a, b) < RTOL * max(Dl, Dr) * 10 or np.abs(b).max() == 0 and np.abs(a).max() == 0
+    refR = mo.transfer_right(GR, s, A, Ab)
+    outR = be.download_env(be.transfer_right(ds, be.upload_env(GR), be.upload(A), be.upload(Ab)), chis)
+    for a, b in zip(outR, refR):
+        assert relerr(a, b) < RTOL * max(Dl, Dr) * 10 or np.abs(b).max() == 0 and np.abs(a).max() == 0
+
+
+@pytest.mark.parametrize("D,d", [(5, 2), (32, 3), (96, 2)])
+def test_transfer_plain_and_regularize(be, D, d):
+    rng = np.random.default_rng(23 + D)
+    A, Ab = rng.standard_normal((D, d, D)), rng.standard_normal((D, d, D))
+    v = rng.standard_normal((D, D))
+    outL = be.download(be.transfer_left(None, be.upload(v[None]).reshape(1, D, D), be.upload(A), be.upload(Ab)))
+    assert relerr(outL[0] if outL.ndim == 3 else outL, mo.transfer_left_bond(v, A, Ab)) < RTOL * D * 10
+    outR = be.download(be.transfer_right(None, be.upload(v[None]).reshape(1, D, D), be.upload(A), be.upload(Ab)))
+    assert relerr(outR[0] if outR.ndim == 3 else outR, mo.transfer_right_bond(v, A, Ab)) < RTOL * D * 10
+    # regularize on a 3-level env
+    env = [rng.standard_normal((D, 1, D)) for _ in range(3)]
+    lvec, rvec = rng.standard_normal((D, D)), rng.standard_normal((D, D))
+    dv = be.upload_env(env)
+    be.regularize(dv, be.upload(lvec), be.upload(rvec))
+    got = be.download_env(dv, [1, 1, 1])
+    for g, e in zip(got, env):
+        assert relerr(g, mo.regularize_env(e, lvec, rvec)) < 1e-12
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB", [(64, 64, 64, 0, 0), (100, 37, 53, 0, 0), (100, 37, 53, 1, 0),
+                                          (100, 37, 53, 0, 1), (100, 37, 53, 1, 1), (256, 128, 512, 1, 0),
+                                          (128, 256, 64, 0, 1), (1, 1, 1, 0, 0), (130, 2, 1000, 1, 1)])
+def test_gemm(be, M, N, K, tA, tB):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if tA else (M, K))
+    B = rng.standard_normal((N, K) if tB else (K, N))
+    C0 = rng.standard_normal((M, N))
+    ref = 0.7 * (A.T if tA else A) @ (B.T if tB else B) - 1.3 * C0
+    out = be.upload(C0)
+    be.gemm(be.upload(A), be.upload(B), transA=bool(tA), transB=bool(tB), alpha=0.7, beta=-1.3, out=out)
+    assert relerr(be.download(out), ref) < RTOL * K
+
+
+def test_vectors(be):
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 1000, 2 ** 20 + 3):
+        xs = [rng.standard_normal(n) for _ in range(11)]
+        y = rng.standard_normal(n)
+        dxs = [be.upload(x) for x in xs]
+        dy = be.upload(y)
+        assert abs(be.dot(dxs[0], dy) - xs[0] @ y) < 1e-12 * n
+        assert abs(be.norm(dy) - np.linalg.norm(y)) < 1e-12 * np.sqrt(n)
+        md = be.multidot(dxs, dy)
+        assert np.allclose(md, [x @ y for x in xs], rtol=0, atol=1e-12 * n)
+        h = be.gs_step(dxs, dy)
+        assert np.allclose(h, md, rtol=0, atol=1e-12 * n)
+        assert relerr(be.download(dy), y - sum(c * x for c, x in zip(md, xs))) < 1e-12
+        z = be.lincomb(dxs, np.arange(1, 12))
+        assert relerr(be.download(z), sum((i + 1) * x for i, x in enumerate(xs))) < 1e-13
+        be.axpby(2.0, dxs[0], -0.5, z)
+        be.scal(3.0, z)
+        assert relerr(be.download(z), 3 * (2 * xs[0] - 0.5 * sum((i + 1) * x for i, x in enumerate(xs)))) < 1e-13
