@@ -123,6 +123,10 @@ int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, 
 int mpsk_gemm(mpsk_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const void* A,
               int64_t lda, const void* B, int64_t ldb, double beta, void* C, int64_t ldc);
 
+/* strided column-major matrix copy dst[r, c] = src[r, c] (index permutations of small tensors, e.g.
+ * AR[k, s, b] <- Vh[k, b, s] after tsvd!: dmrg.jl:104 `_transpose_front(ar)`) */
+int mpsk_copy2d(mpsk_ctx* ctx, int rows, int cols, const void* src, int64_t lds, void* dst, int64_t ldd);
+
 /* ---- Krylov vector protocol (VectorInterface: inner / add!! / scale!! / zerovector) -----------
  * KrylovKit needs these of the iterate type (quasiparticle_state.jl:357-411 is the in-repo example). */
 int mpsk_vdot(mpsk_ctx* ctx, int64_t n, const void* x, const void* y, double* host_out);

@@ -58,6 +58,7 @@ SIGNATURES = {
                   C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p],
     "mpsk_gemm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
                   C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64],
+    "mpsk_copy2d": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
     "mpsk_vdot": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, c_double_p],
     "mpsk_vnrm2": [C.c_void_p, C.c_int64, C.c_void_p, c_double_p],
     "mpsk_vaxpby": [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_double, C.c_void_p],

@@ -1,0 +1,292 @@
+"""Ground-state drivers with the reference's API: find_groundstate(psi, H, DMRG()/DMRG2()/VUMPS())
+(src/algorithms/groundstate/dmrg.jl:14-141, vumps.jl:18-92, find_groundstate.jl:19-41), plus
+calc_galerkin (toolbox.jl:17-25) and expectation_value (expval.jl:92-124).  Orchestration only:
+every flop happens inside libmpsk."""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .backend import DTensor
+from .derivatives import ddAC, ddAC2, ddC
+from .environments import FinEnv, MPOHamInfEnv, environments
+from .states import FiniteMPS, InfiniteMPS, leftorth, mul_AC
+from . import krylov
+
+
+@dataclass
+class Arnoldi:  # Defaults.eigsolver  (defaults.jl:33)
+    tol: float = 1e-12
+    maxiter: int = 100
+    krylovdim: int = 30
+    eager: bool = True
+    fixed_matvecs: int | None = None   # benchmark mode: exactly this many matvecs per solve
+
+
+@dataclass
+class DMRG:  # dmrg.jl:14-20
+    tol: float = 1e-12
+    maxiter: int = 100
+    eigalg: Arnoldi = field(default_factory=Arnoldi)
+    verbosity: int = 0
+    finalize: object = None
+
+
+@dataclass
+class DMRG2:  # dmrg.jl:71-78
+    tol: float = 1e-12
+    maxiter: int = 100
+    eigalg: Arnoldi = field(default_factory=Arnoldi)
+    trunc_dim: int = 0            # truncdim(D); 0 = no limit
+    trunc_err: float = 1e-6       # truncerr(1e-6) default (dmrg.jl:75); ignored when trunc_dim > 0 unless set
+    verbosity: int = 0
+    finalize: object = None
+
+
+@dataclass
+class VUMPS:  # vumps.jl:18-27 with the dynamic tolerances of defaults.jl:38-57
+    tol: float = 1e-12
+    maxiter: int = 100
+    verbosity: int = 0
+    krylovdim: int = 30
+    eig_tol_min: float = 1e-12
+    eig_tol_max: float = 1e-5
+    eig_tol_factor: float = 1e-5
+    gauge_tol_min: float = 1e-14
+    gauge_tol_max: float = 1e-5
+    gauge_tol_factor: float = 1e-8
+    env_tol_min: float = 1e-12
+    env_tol_max: float = 1e-5
+    env_tol_factor: float = 1e-5
+    finalize: object = None
+
+
+def updatetol(tol_min, tol_max, factor, it, eps):  # dynamictols.jl:50-53
+    return min(max(eps * factor / math.sqrt(it), tol_min), tol_max)
+
+
+def fixedpoint(be, A, x0, alg: Arnoldi, ws=None):
+    """fixedpoint(A, x0, :SR, alg)  (fixedpoint.jl:19-30); non-convergence only warns."""
+    lam, vec, nmv, res = krylov.eigsolve_sr(be, A, x0, tol=alg.tol, krylovdim=alg.krylovdim,
+                                            maxiter=alg.maxiter, fixed_matvecs=alg.fixed_matvecs, ws=ws)
+    return lam, vec
+
+
+# ---- measurements ------------------------------------------------------------------------------
+
+def calc_galerkin(psi, pos, envs):
+    """|| (1 - AL AL^dag) normalize(H_AC AC) ||   (toolbox.jl:17-22)."""
+    be = psi.be
+    if isinstance(psi, FiniteMPS):
+        ac, al = psi.AC(pos), psi.AL(pos)
+        h = ddAC(pos, psi, envs.H, envs)
+    else:
+        ac, al = psi.AC[pos], psi.AL[pos]
+        h = ddAC(pos, psi, envs.H, envs)
+    g = h(ac)
+    be.scal(1.0 / be.norm(g), g)
+    Dl, d, Dr = al.shape
+    alm, gm = al.reshape(Dl * d, Dr), g.reshape(Dl * d, g.shape[2])
+    t = be.gemm(alm, gm, transA=True)
+    be.gemm(alm, t, alpha=-1.0, beta=1.0, out=gm)
+    return be.norm(gm)
+
+
+def expectation_value(psi, H, envs):
+    """Per-site energies (expval.jl:92-109 finite, :111-124 infinite)."""
+    be = psi.be
+    if isinstance(psi, FiniteMPS):
+        L = len(psi)
+        ens = np.zeros(L)
+        for i in range(L):
+            ac = psi.AC(i)
+            y = be.dAC(H.energy_slice(i), envs.leftenv(i, psi), envs.rightenv(i, psi), ac)
+            ens[i] = be.dot(ac, y)
+        n2 = be.norm(psi.AC(L - 1)) ** 2
+        return ens / n2
+    n, odim = len(psi), H.odim
+    ens = np.zeros(n)
+    for i in range(n):
+        GL = envs.leftenv(i, psi)
+        # last column of H[i] applied to the left env, closed with r_LL = C C^dag  (expval.jl:111-124)
+        col = {(j, 0): H[i].blocks[(j, odim - 1)] for j in range(odim) if H[i].contains(j, odim - 1)}
+        blk = be.mposlice(odim, H.d, H[i].chil, [H[i].chir[odim - 1]] + [1] * (odim - 1), col)
+        apl = be.transfer_left(blk, GL, psi.AL[i], psi.AL[i])
+        c = psi.CR[i]
+        r = be.gemm(c, c, transB=True)
+        first = DTensor(apl.buf, (apl.shape[1], apl.shape[2]))   # slab 0
+        ens[i] = be.dot(first, DTensor(r.buf, first.shape))      # sum apl[x,y] r[y,x], r symmetric
+    return ens
+
+
+# ---- DMRG ---------------------------------------------------------------------------------------
+
+def _log(alg, name, it, E, eps, t0):
+    if alg.verbosity >= 3:
+        print(f"[ Info: {name} {it:3d}:\tobj = {E:+.12e}\terr = {eps:.10e}\ttime = {time.time() - t0:.2f} sec", flush=True)
+
+
+def find_groundstate(psi, H, alg=None, envs=None):
+    """find_groundstate(psi, H, alg[, envs]) -> (psi, envs, eps)  (find_groundstate.jl:19-41)."""
+    if alg is None:
+        alg = DMRG() if isinstance(psi, FiniteMPS) else VUMPS()
+    if isinstance(alg, DMRG):
+        return _dmrg(psi.copy(), H, alg, envs)
+    if isinstance(alg, DMRG2):
+        return _dmrg2(psi.copy(), H, alg, envs)
+    if isinstance(alg, VUMPS):
+        return _vumps(psi, H, alg, envs)
+    raise TypeError(f"unknown algorithm {alg!r}")
+
+
+def _dmrg(psi, H, alg: DMRG, envs=None):  # dmrg.jl:22-55
+    be = psi.be
+    envs = FinEnv(psi, H) if envs is None else envs
+    L = len(psi)
+    ws = krylov.KrylovWorkspace(be)
+    eps_s = [calc_galerkin(psi, p, envs) for p in range(L)]
+    eps = max(eps_s)
+    t0 = time.time()
+    history = []
+    for it in range(1, alg.maxiter + 1):
+        eps_s = [0.0] * L
+        for pos in list(range(0, L - 1)) + list(range(L - 1, 0, -1)):
+            h = ddAC(pos, psi, H, envs)
+            _, vec = fixedpoint(be, h, psi.AC(pos), alg.eigalg, ws)
+            eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs))
+            psi.set_AC(pos, vec)
+        eps = max(eps_s)
+        if alg.finalize is not None:
+            psi, envs = alg.finalize(it, psi, H, envs)
+        if alg.verbosity >= 3 or eps <= alg.tol or it == alg.maxiter:
+            E = float(np.sum(expectation_value(psi, H, envs)))
+            history.append((it, E, eps))
+            _log(alg, "DMRG", it, E, eps, t0)
+        if eps <= alg.tol:
+            break
+    envs.history = history
+    return psi, envs, eps
+
+
+def _two_site_tensor(be, left: DTensor, right: DTensor):
+    """theta[a,s1,b,s2] = sum_m left[a,s1,m] right[m,s2,b]   (dmrg.jl:92 / :108)."""
+    Dl, d1, Dm = left.shape
+    _, d2, Dr = right.shape
+    theta = be.empty(Dl, d1, Dr, d2)
+    lm = left.reshape(Dl * d1, Dm)
+    for s2 in range(d2):
+        # right[:, s2, :] is a (Dm x Dr) matrix with leading dimension Dm*d2 at offset s2*Dm
+        be.gemm_raw(False, False, Dl * d1, Dr, Dm, 1.0, lm.ptr, Dl * d1, right.ptr + 8 * s2 * Dm, Dm * d2, 0.0,
+                    theta.ptr + 8 * s2 * Dl * d1 * Dr, Dl * d1)
+    return theta
+
+
+def _dmrg2(psi, H, alg: DMRG2, envs=None):  # dmrg.jl:80-137
+    be = psi.be
+    envs = FinEnv(psi, H) if envs is None else envs
+    L = len(psi)
+    ws = krylov.KrylovWorkspace(be)
+    eps = np.inf
+    t0 = time.time()
+    history = []
+    trunc_err = alg.trunc_err if alg.trunc_dim <= 0 else 0.0
+
+    def update(pos, ac2):
+        h = ddAC2(pos, psi, H, envs)
+        _, new = fixedpoint(be, h, ac2, alg.eigalg, ws)
+        Dl, d1, Dr, d2 = new.shape
+        U, S, Vh, kept, _ = be.tsvd(new.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
+        k = kept
+        # normalize!(c)
+        Sk = DTensor(S.buf, (k,))
+        be.scal(1.0 / be.norm(Sk), Sk)
+        s_host = be.download(Sk)
+        c = be.upload(np.diag(s_host))
+        al = DTensor(U.buf, (Dl, d1, k))                      # first k columns of U (ld = Dl*d1)
+        # ar[k, s2, b] = Vh[k, b, s2] : d2 strided copies out of Vh (ld = kmax)
+        kmax = Vh.shape[0]
+        ar = be.empty(k, d2, Dr)
+        for s2 in range(d2):
+            be.copy2d(k, Dr, Vh.ptr + 8 * s2 * kmax * Dr, kmax, ar.ptr + 8 * s2 * k, k * d2)
+        # fidelity  v = <ac2, al c ar>   (dmrg.jl:98-100)
+        us = be.gemm(al.reshape(Dl * d1, k), c)
+        rec = be.empty(Dl, d1, Dr, d2)
+        be.gemm_raw(False, False, Dl * d1, Dr * d2, k, 1.0, us.ptr, Dl * d1, Vh.ptr, kmax, 0.0, rec.ptr, Dl * d1)
+        v = be.dot(ac2, rec)
+        return al, c, ar, abs(1 - abs(v))
+
+    for it in range(1, alg.maxiter + 1):
+        eps_s = [0.0] * L
+        for pos in range(0, L - 1):
+            ac2 = _two_site_tensor(be, psi.AC(pos), psi.AR(pos + 1))
+            al, c, ar, e = update(pos, ac2)
+            eps_s[pos] = max(eps_s[pos], e)
+            psi.set_AC(pos, (al, c))
+            psi.set_AC(pos + 1, (c, ar))
+        for pos in range(L - 3, -1, -1):
+            ac2 = _two_site_tensor(be, psi.AL(pos), psi.AC(pos + 1))
+            al, c, ar, e = update(pos, ac2)
+            eps_s[pos] = max(eps_s[pos], e)
+            psi.set_AC(pos + 1, (c, ar))
+            psi.set_AC(pos, (al, c))
+        eps = max(eps_s)
+        if alg.finalize is not None:
+            psi, envs = alg.finalize(it, psi, H, envs)
+        if alg.verbosity >= 3 or eps <= alg.tol or it == alg.maxiter:
+            E = float(np.sum(expectation_value(psi, H, envs)))
+            history.append((it, E, eps))
+            _log(alg, "DMRG2", it, E, eps, t0)
+        if eps <= alg.tol:
+            break
+    envs.history = history
+    return psi, envs, eps
+
+
+# ---- VUMPS ----------------------------------------------------------------------------------------
+
+def regauge(be, AC: DTensor, C: DTensor):
+    """regauge!(AC, C; alg = QRpos()) -> AL = Q_AC Q_C^dag   (ortho.jl:127-131)."""
+    Dl, d, Dr = AC.shape
+    Qac, _ = be.qrpos(AC.reshape(Dl * d, Dr))
+    Qc, _ = be.qrpos(C)
+    return be.gemm(Qac, Qc, transB=True).reshape(Dl, d, Dr)
+
+
+def _calc_galerkin_inf(psi, envs):
+    return max(calc_galerkin(psi, loc, envs) for loc in range(len(psi)))
+
+
+def _vumps(psi, H, alg: VUMPS, envs=None):  # vumps.jl:29-92
+    be = psi.be
+    envs = MPOHamInfEnv(psi, H) if envs is None else envs
+    eps = _calc_galerkin_inf(psi, envs)
+    n = len(psi)
+    ws = krylov.KrylovWorkspace(be)
+    t0 = time.time()
+    history = []
+    for it in range(1, alg.maxiter + 1):
+        eig = Arnoldi(tol=updatetol(alg.eig_tol_min, alg.eig_tol_max, alg.eig_tol_factor, it, eps),
+                      krylovdim=alg.krylovdim)
+        newAL = []
+        for loc in range(n):
+            _, AC = fixedpoint(be, ddAC(loc, psi, H, envs), psi.AC[loc], eig, ws)
+            _, C = fixedpoint(be, ddC(loc, psi, H, envs), psi.CR[loc], eig, ws)
+            newAL.append(regauge(be, AC, C))
+        gtol = updatetol(alg.gauge_tol_min, alg.gauge_tol_max, alg.gauge_tol_factor, it, eps)
+        psi = InfiniteMPS.from_AL(newAL, psi.CR[n - 1], tol=gtol, be=be)
+        etol = updatetol(alg.env_tol_min, alg.env_tol_max, alg.env_tol_factor, it, eps)
+        envs.recalculate(psi, etol)
+        if alg.finalize is not None:
+            psi, envs = alg.finalize(it, psi, H, envs)
+        eps = _calc_galerkin_inf(psi, envs)
+        if alg.verbosity >= 3 or eps <= alg.tol or it == alg.maxiter:
+            E = float(np.sum(expectation_value(psi, H, envs)))
+            history.append((it, E, eps))
+            _log(alg, "VUMPS", it, E, eps, t0)
+        if eps <= alg.tol:
+            break
+    envs.history = history
+    return psi, envs, eps

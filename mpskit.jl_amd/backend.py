@@ -207,6 +207,13 @@ class Backend:
                                  c.ptr, M if ldc is None else ldc), "mpsk_gemm")
         return c
 
+    def gemm_raw(self, transA, transB, M, N, K, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc):
+        check(self.lib.mpsk_gemm(self.ctx, int(transA), int(transB), M, N, K, float(alpha), a_ptr, lda, b_ptr,
+                                 ldb, float(beta), c_ptr, ldc), "mpsk_gemm")
+
+    def copy2d(self, rows, cols, src_ptr, lds, dst_ptr, ldd):
+        check(self.lib.mpsk_copy2d(self.ctx, rows, cols, src_ptr, lds, dst_ptr, ldd), "mpsk_copy2d")
+
     # ---- gauge -------------------------------------------------------------------------------
     def qrpos(self, A: DTensor):
         m, n = A.shape

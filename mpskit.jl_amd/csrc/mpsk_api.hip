@@ -43,6 +43,7 @@ struct mpsk_ctx {
   double* d_scal = nullptr;     // [MAXK] device scalars
   double* d_partial = nullptr;  // dot scratch
   double* h_scal = nullptr;     // pinned host mirror
+  int last_svd_sweeps = 0;
   std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
 };
 constexpr int MAXK = 256;
@@ -442,14 +443,52 @@ int mpsk_regularize(mpsk_ctx* c, int W, int D1, int D2, void* v, const void* lve
 }
 
 int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
-  return fail(MPSK_ERR_UNSUPPORTED, "mpsk_qrpos: not implemented yet");
+  REQUIRE(c && A && Q && R, "NULL argument");
+  REQUIRE(m >= n && n > 0, "needs m >= n > 0");
+  REQUIRE(lda >= m && ldq >= m && ldr >= n, "leading dimension too small");
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = ensure_ws(c, sizeof(double) * qrpos_workspace_doubles(m, n))) return rc;
+  std::string err;
+  hipError_t e = qrpos(m, n, (const double*)A, lda, (double*)Q, ldq, (double*)R, ldr, (double*)c->ws, c->stream, &err);
+  if (e != hipSuccess) return fail(err.empty() ? MPSK_ERR_HIP : MPSK_ERR_INVALID, "mpsk_qrpos: " + (err.empty() ? std::string(hipGetErrorString(e)) : err));
+  return MPSK_OK;
 }
+
+// LQ of A (m x n, m <= n) through the QR of A^T:  A^T = Qt Rt  ->  L = Rt^T, Q = Qt^T
 int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq) {
-  return fail(MPSK_ERR_UNSUPPORTED, "mpsk_lqpos: not implemented yet");
+  REQUIRE(c && A && Q && L, "NULL argument");
+  REQUIRE(m <= n && m > 0, "needs 0 < m <= n");
+  REQUIRE(lda >= m && ldq >= m && ldl >= m, "leading dimension too small");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t qws = qrpos_workspace_doubles(n, m);
+  const size_t extra = (size_t)2 * n * m + (size_t)m * m;
+  if (int rc = ensure_ws(c, sizeof(double) * (qws + extra))) return rc;
+  double* At = (double*)c->ws;            // n x m
+  double* Qt = At + (size_t)n * m;        // n x m
+  double* Rt = Qt + (size_t)n * m;        // m x m
+  double* ws2 = Rt + (size_t)m * m;
+  HIPCHK(transpose((const double*)A, lda, m, n, At, n, c->stream));
+  std::string err;
+  hipError_t e = qrpos(n, m, At, n, Qt, n, Rt, m, ws2, c->stream, &err);
+  if (e != hipSuccess) return fail(err.empty() ? MPSK_ERR_HIP : MPSK_ERR_INVALID, "mpsk_lqpos: " + (err.empty() ? std::string(hipGetErrorString(e)) : err));
+  HIPCHK(transpose(Qt, n, n, m, (double*)Q, ldq, c->stream));
+  HIPCHK(transpose(Rt, m, m, m, (double*)L, ldl, c->stream));
+  return MPSK_OK;
 }
 int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, int ldu, void* S, void* Vh,
               int ldv, int max_keep, double trunc_err, int* kept, double* disc_norm) {
-  return fail(MPSK_ERR_UNSUPPORTED, "mpsk_tsvd: not implemented yet");
+  REQUIRE(c && theta && U && S && Vh && kept && disc_norm, "NULL argument");
+  REQUIRE(m > 0 && n > 0, "dimensions must be positive");
+  const int kmax = m < n ? m : n;
+  REQUIRE(ldt >= m && ldu >= m && ldv >= kmax, "leading dimension too small");
+  REQUIRE(trunc_err >= 0.0, "trunc_err must be >= 0");
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = ensure_ws(c, tsvd_workspace_bytes(m, n))) return rc;
+  std::string err;
+  hipError_t e = tsvd(m, n, (const double*)theta, ldt, (double*)U, ldu, (double*)S, (double*)Vh, ldv, max_keep,
+                      trunc_err, kept, disc_norm, c->ws, c->stream, &err, &c->last_svd_sweeps);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + hipGetErrorString(e));
+  return MPSK_OK;
 }
 
 int mpsk_gemm(mpsk_ctx* c, int transA, int transB, int M, int N, int K, double alpha, const void* A, int64_t lda,
@@ -460,6 +499,14 @@ int mpsk_gemm(mpsk_ctx* c, int transA, int transB, int M, int N, int K, double a
   GemmArgs g = mk((const double*)A, (const double*)B, (double*)C, M, N, K, lda, ldb, ldc, transA ? 1 : 0, transB ? 1 : 0);
   g.alpha = alpha; g.beta = beta;
   HIPCHK(gemm_f64(g, c->stream));
+  return MPSK_OK;
+}
+
+int mpsk_copy2d(mpsk_ctx* c, int rows, int cols, const void* src, int64_t lds, void* dst, int64_t ldd) {
+  REQUIRE(c && src && dst, "NULL argument");
+  REQUIRE(rows > 0 && cols > 0 && lds >= rows && ldd >= rows, "bad dimensions");
+  HIPCHK(hipMemcpy2DAsync(dst, sizeof(double) * ldd, src, sizeof(double) * lds, sizeof(double) * rows, cols,
+                          hipMemcpyDeviceToDevice, c->stream));
   return MPSK_OK;
 }
 

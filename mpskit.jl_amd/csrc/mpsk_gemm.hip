@@ -113,9 +113,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
   const int z = blockIdx.y;
   const int m0 = bm * BM, n0 = bn * BN;
 
-  const double* Ab = g.A + (int64_t)z * g.bsA;
-  const double* Bb = g.B + (int64_t)z * g.bsB;
-  double* Cb = g.C + (int64_t)z * g.bsC;
+  const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
+  const double* Bb = g.B + (g.tabB ? g.tabB[z] : (int64_t)z * g.bsB);
+  double* Cb = g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC);
 
   d4 acc[TM][TN];
 #pragma unroll
@@ -244,6 +244,7 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   bool aligned = (g.M % bm == 0) && (g.N % bn == 0) && (g.K % BK == 0) && (g.lda % 2 == 0) &&
                  (g.ldb % 2 == 0) && (g.bsA % 2 == 0) && (g.bsB % 2 == 0) &&
                  ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
+  if (g.tabA || g.tabB) aligned = aligned && g.tabs_even;
   for (int i = 0; i < g.nseg; ++i) aligned = aligned && (g.segA[i] % 2 == 0) && (g.segB[i] % 2 == 0);
 #define MPSK_DISPATCH(TA_, TB_)                                                        \
   return aligned ? launch_tile<TA_, TB_, true>(g, bm, bn, s) : launch_tile<TA_, TB_, false>(g, bm, bn, s)

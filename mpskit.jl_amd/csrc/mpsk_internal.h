@@ -22,6 +22,11 @@ struct GemmArgs {
   int64_t segA[MAXSEG], segB[MAXSEG];  // element offsets of each K-segment
   double alpha, beta;
   int transA, transB;        // 0: col-major as given; 1: operand is the transpose of a col-major matrix
+  // optional per-batch element offsets (device arrays of length batch); override bsA/bsB/bsC when set
+  const int64_t* tabA;
+  const int64_t* tabB;
+  const int64_t* tabC;
+  int tabs_even;             // caller guarantees every tabA/tabB entry is even (16-B aligned operands)
 };
 
 hipError_t gemm_f64(const GemmArgs& g, hipStream_t s);
@@ -63,5 +68,14 @@ hipError_t vec_multiaxpy(const double* const* xs, const double* d_coefs, int k, 
 
 // ---- gauge kernels ----------------------------------------------------------------------------
 hipError_t regularize(int W, int D1, int D2, double* v, const double* lvec, const double* rvec, hipStream_t s);
+hipError_t transpose(const double* in, int ldi, int rows, int cols, double* out, int ldo, hipStream_t s);
+size_t qrpos_workspace_doubles(int m, int n);
+hipError_t qrpos(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
+                 hipStream_t s, std::string* err);
+
+size_t tsvd_workspace_bytes(int m, int n);
+hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
+                int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,
+                std::string* err, int* sweeps_out);
 
 }  // namespace mpsk

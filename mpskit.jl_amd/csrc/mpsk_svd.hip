@@ -1,0 +1,367 @@
+// Truncated SVD for the two-site update (tsvd!(theta; trunc, alg = SVD()) at dmrg.jl:96,112 and
+// tdvp.jl:124,140 of the reference): one-sided BLOCK JACOBI (Hestenes) on the MFMA GEMM core.
+//
+//   G <- theta (m x n, m >= n, columns padded to a multiple of 64), V <- I.
+//   The n/32 column blocks are paired by a round-robin tournament.  Per round, for every pair p
+//   (64 adjacent columns X_p of G):
+//     1. Gram   M_p = X_p^T X_p             -- batched TN GEMM, K split over Q workgroups
+//     2. eig    M_p = W_p L W_p^T           -- cyclic two-sided Jacobi in LDS, one workgroup / pair
+//     3. update X_p <- X_p W_p, V_p <- V_p W_p, written straight to next round's slots
+//        (ping-pong buffers; the tournament permutation is folded into the GEMM's C offsets)
+//   until every off-diagonal Gram entry satisfies |g_ij| <= tol sqrt(g_ii g_jj).
+//   Then sigma_j = ||G_j||, U = G diag(1/sigma), sorted descending on the host.
+// Jacobi keeps high RELATIVE accuracy of small singular values (they decide truncerr/truncdim),
+// which a Gram-matrix eigensolve of the whole theta would not.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+#include "mpsk_internal.h"
+
+namespace mpsk {
+
+constexpr int JB = 32;
+constexpr int J2 = 64;
+
+__global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restrict__ Mpart, int Q,
+                                                         double* __restrict__ Wout, double tol,
+                                                         unsigned long long* __restrict__ flag) {
+  __shared__ double Ms[J2][J2 + 1];
+  __shared__ double Ws[J2][J2 + 1];
+  __shared__ double cs_c[J2 / 2], cs_s[J2 / 2];
+  __shared__ int cs_p[J2 / 2], cs_q[J2 / 2];
+  __shared__ double red[4];
+  __shared__ int any_rot;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  const double* Mp = Mpart + (size_t)p * Q * J2 * J2;
+  for (int e = tid; e < J2 * J2; e += 256) {
+    double s = 0.0;
+    for (int q = 0; q < Q; ++q) s += Mp[(size_t)q * J2 * J2 + e];
+    Ms[e % J2][e / J2] = s;          // Ms[i][j], column-major source
+    Ws[e % J2][e / J2] = (e % J2 == e / J2) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // symmetrise + convergence measure of this pair
+  double mx = 0.0;
+  for (int e = tid; e < J2 * J2; e += 256) {
+    int i = e % J2, j = e / J2;
+    if (i < j) {
+      double a = 0.5 * (Ms[i][j] + Ms[j][i]);
+      double dd = Ms[i][i] * Ms[j][j];
+      double r = (a == 0.0) ? 0.0 : (dd > 0.0 ? fabs(a) / sqrt(dd) : 1.0);
+      mx = fmax(mx, r);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (tid == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(mx));
+  double* Wp = Wout + (size_t)p * J2 * J2;
+  if (mx <= tol) {
+    for (int e = tid; e < J2 * J2; e += 256) Wp[e] = (e % J2 == e / J2) ? 1.0 : 0.0;
+    return;
+  }
+  __syncthreads();
+  for (int e = tid; e < J2 * J2; e += 256) {
+    int i = e % J2, j = e / J2;
+    if (i < j) { double a = 0.5 * (Ms[i][j] + Ms[j][i]); Ms[i][j] = a; }
+  }
+  __syncthreads();
+  for (int e = tid; e < J2 * J2; e += 256) {
+    int i = e % J2, j = e / J2;
+    if (i > j) Ms[i][j] = Ms[j][i];
+  }
+  __syncthreads();
+
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    if (tid == 0) any_rot = 0;
+    __syncthreads();
+    for (int st = 0; st < J2 - 1; ++st) {
+      if (tid < J2 / 2) {
+        int pp, qq;
+        if (tid == 0) { pp = J2 - 1; qq = st; }
+        else { pp = (st + tid) % (J2 - 1); qq = (st + (J2 - 1) - tid) % (J2 - 1); }
+        if (pp > qq) { int t = pp; pp = qq; qq = t; }
+        const double app = Ms[pp][pp], aqq = Ms[qq][qq], apq = Ms[pp][qq];
+        double c = 1.0, s = 0.0;
+        if (apq != 0.0 && fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq))) {
+          const double zeta = (aqq - app) / (2.0 * apq);
+          const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          c = 1.0 / sqrt(1.0 + t * t);
+          s = c * t;
+          if (fabs(apq) > 2.3e-16 * sqrt(fabs(app * aqq))) any_rot = 1;
+        }
+        cs_c[tid] = c; cs_s[tid] = s; cs_p[tid] = pp; cs_q[tid] = qq;
+      }
+      __syncthreads();
+      // columns:  M <- M J,  W <- W J
+      for (int e = tid; e < (J2 / 2) * J2; e += 256) {
+        const int k = e / J2, r = e % J2;
+        const double c = cs_c[k], s = cs_s[k];
+        const int pp = cs_p[k], qq = cs_q[k];
+        const double mp = Ms[r][pp], mq = Ms[r][qq];
+        Ms[r][pp] = c * mp - s * mq;
+        Ms[r][qq] = s * mp + c * mq;
+        const double wp = Ws[r][pp], wq = Ws[r][qq];
+        Ws[r][pp] = c * wp - s * wq;
+        Ws[r][qq] = s * wp + c * wq;
+      }
+      __syncthreads();
+      // rows:  M <- J^T M
+      for (int e = tid; e < (J2 / 2) * J2; e += 256) {
+        const int k = e / J2, r = e % J2;
+        const double c = cs_c[k], s = cs_s[k];
+        const int pp = cs_p[k], qq = cs_q[k];
+        const double mp = Ms[pp][r], mq = Ms[qq][r];
+        Ms[pp][r] = c * mp - s * mq;
+        Ms[qq][r] = s * mp + c * mq;
+      }
+      __syncthreads();
+      if (tid < J2 / 2) {   // the rotated off-diagonal entry is exactly annihilated
+        if (cs_s[tid] != 0.0) { Ms[cs_p[tid]][cs_q[tid]] = 0.0; Ms[cs_q[tid]][cs_p[tid]] = 0.0; }
+      }
+      __syncthreads();
+    }
+    if (!any_rot) break;
+    __syncthreads();
+  }
+  // One Newton-Schulz step  W <- W (3 I - W^T W) / 2  removes the O(#rotations * eps) drift of
+  // W's orthogonality, so the accumulated V (and G = theta V) stay orthogonal over ~10^3 rounds.
+  __syncthreads();
+  for (int e = tid; e < J2 * J2; e += 256) {
+    const int i = e % J2, j = e / J2;
+    double t = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < J2; ++r) t += Ws[r][i] * Ws[r][j];
+    Ms[i][j] = t;
+  }
+  __syncthreads();
+  for (int e = tid; e < J2 * J2; e += 256) {
+    const int i = e % J2, j = e / J2;
+    double t = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < J2; ++r) t += Ws[i][r] * Ms[r][j];
+    Wp[e] = 1.5 * Ws[i][j] - 0.5 * t;
+  }
+}
+
+// sigma2[j] = sum_r G[r, j]^2   (one workgroup per column)
+__global__ __launch_bounds__(256) void colnorm2_kernel(const double* __restrict__ G, int ldg, int m,
+                                                       double* __restrict__ sigma2) {
+  __shared__ double red[4];
+  const double* g = G + (size_t)blockIdx.x * ldg;
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < m; r += 256) acc += g[r] * g[r];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) sigma2[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out(r, i) [+transposed store] = src[r, perm[i]] * scale[i]
+__global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restrict__ src, int lds_, int rows,
+                                                          const int* __restrict__ perm, const double* __restrict__ scale,
+                                                          int k, double* __restrict__ out, int ldo, int transposed) {
+  const int64_t total = (int64_t)rows * k;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e % rows), i = (int)(e / rows);
+    double v = src[r + (size_t)perm[i] * lds_];
+    if (scale) v *= scale[i];
+    if (transposed) out[i + (size_t)r * ldo] = v;
+    else out[r + (size_t)i * ldo] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void svd_init_kernel(const double* __restrict__ theta, int ldt, int m, int n,
+                                                       int transposed, double* __restrict__ G, int mm, int npad,
+                                                       double* __restrict__ V, int nn) {
+  // G (mm x npad) = theta or theta^T, zero padded ; V (nn x npad) = [I 0]
+  const int64_t tg = (int64_t)mm * npad, tv = (int64_t)nn * npad;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tg + tv; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < tg) {
+      int r = (int)(e % mm), c = (int)(e / mm);
+      double v = 0.0;
+      if (c < nn) v = transposed ? theta[c + (size_t)r * ldt] : theta[r + (size_t)c * ldt];
+      G[e] = v;
+    } else {
+      int64_t f = e - tg;
+      int r = (int)(f % nn), c = (int)(f / nn);
+      V[f] = (r == c) ? 1.0 : 0.0;
+    }
+  }
+}
+
+struct SvdPlan {
+  int mm, nn, npad, P, Q, transposed;
+  size_t bytes;
+};
+
+static SvdPlan svd_plan(int m, int n) {
+  SvdPlan p;
+  p.transposed = (m < n);
+  p.mm = p.transposed ? n : m;
+  p.nn = p.transposed ? m : n;
+  p.npad = ((p.nn + J2 - 1) / J2) * J2;
+  p.P = p.npad / J2;
+  int target = 512 / p.P;            // aim at ~512 Gram tiles per round
+  if (target < 1) target = 1;
+  if (target > 16) target = 16;
+  int q = 1;                         // largest divisor of mm <= target with >= 128 (even) rows per split
+  for (int c = target; c >= 2; --c)
+    if (p.mm % c == 0 && (p.mm / c) % 2 == 0 && p.mm / c >= 128) { q = c; break; }
+  p.Q = q;
+  size_t d = (size_t)2 * p.mm * p.npad + (size_t)2 * p.nn * p.npad + (size_t)p.P * p.Q * J2 * J2 +
+             (size_t)p.P * J2 * J2 + (size_t)p.npad * 2 + 64;
+  size_t tabs = (size_t)8 * (2 * p.P) * sizeof(int64_t) + (size_t)p.P * p.Q * 2 * sizeof(int64_t) + 256;
+  p.bytes = d * sizeof(double) + tabs + (size_t)p.npad * sizeof(int);
+  return p;
+}
+
+size_t tsvd_workspace_bytes(int m, int n) { return svd_plan(m, n).bytes; }
+
+// Host-synchronising truncated SVD; see include/mpsk.h (mpsk_tsvd) for the contract.
+hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
+                int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,
+                std::string* err, int* sweeps_out) {
+  const SvdPlan pl = svd_plan(m, n);
+  const int mm = pl.mm, nn = pl.nn, npad = pl.npad, P = pl.P, Q = pl.Q;
+  const int kmax = std::min(m, n);
+  double* G[2]; double* V[2];
+  double* base = (double*)ws;
+  G[0] = base; G[1] = G[0] + (size_t)mm * npad;
+  V[0] = G[1] + (size_t)mm * npad; V[1] = V[0] + (size_t)nn * npad;
+  double* Mpart = V[1] + (size_t)nn * npad;
+  double* Wm = Mpart + (size_t)P * Q * J2 * J2;
+  double* sigma2 = Wm + (size_t)P * J2 * J2;
+  double* scale = sigma2 + npad;
+  unsigned long long* flag = (unsigned long long*)(scale + npad);
+  int64_t* tabs = (int64_t*)(flag + 8);
+  // tables (device): gram: A/B offsets per (p,q) and C offsets; update: A (pair), B (W half), C (dest slot)
+  int64_t* t_gramA = tabs;                 // P*Q
+  int64_t* t_gramC = t_gramA + (size_t)P * Q;  // P*Q
+  int64_t* t_updA_G = t_gramC + (size_t)P * Q; // 2P
+  int64_t* t_updA_V = t_updA_G + 2 * P;
+  int64_t* t_updB = t_updA_V + 2 * P;
+  int64_t* t_updC_G = t_updB + 2 * P;
+  int64_t* t_updC_V = t_updC_G + 2 * P;
+  int* d_perm = (int*)(t_updC_V + 2 * P);
+
+  // round-robin tournament on 2P blocks: slot 2p = top[p], 2p+1 = bottom[p]
+  auto dest_slot = [&](int p, int half) -> int {
+    if (P == 1) return half;
+    if (half == 0) {                       // top[p]
+      if (p == 0) return 0;
+      if (p + 1 <= P - 1) return 2 * (p + 1);
+      return 2 * (P - 1) + 1;              // top[P-1] -> bottom[P-1]
+    }
+    if (p == 0) return 2 * 1;              // bottom[0] -> top[1]
+    return 2 * (p - 1) + 1;                // bottom[p] -> bottom[p-1]
+  };
+  const int kq = mm / Q;                   // rows per K-split (Q divides mm by construction)
+  std::vector<int64_t> h((size_t)2 * P * Q + 10 * P);
+  int64_t* hgA = h.data(); int64_t* hgC = hgA + (size_t)P * Q;
+  int64_t* huAG = hgC + (size_t)P * Q; int64_t* huAV = huAG + 2 * P; int64_t* huB = huAV + 2 * P;
+  int64_t* huCG = huB + 2 * P; int64_t* huCV = huCG + 2 * P;
+  for (int p = 0; p < P; ++p) {
+    for (int q = 0; q < Q; ++q) {
+      hgA[p * Q + q] = (int64_t)p * J2 * mm + (int64_t)q * kq;
+      hgC[p * Q + q] = ((int64_t)p * Q + q) * J2 * J2;
+    }
+    for (int hf = 0; hf < 2; ++hf) {
+      huAG[2 * p + hf] = (int64_t)p * J2 * mm;
+      huAV[2 * p + hf] = (int64_t)p * J2 * nn;
+      huB[2 * p + hf] = (int64_t)p * J2 * J2 + (int64_t)hf * JB * J2;
+      huCG[2 * p + hf] = (int64_t)dest_slot(p, hf) * JB * mm;
+      huCV[2 * p + hf] = (int64_t)dest_slot(p, hf) * JB * nn;
+    }
+  }
+  hipError_t e;
+  if ((e = hipMemcpyAsync(tabs, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(svd_init_kernel, dim3(2048), dim3(256), 0, s, theta, ldt, m, n, pl.transposed, G[0], mm, npad,
+                     V[0], nn);
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;   // h goes out of scope later; keep it simple
+
+  const bool kq_even = (kq % 2 == 0) && (mm % 2 == 0) && (nn % 2 == 0);
+  const double tol = std::sqrt((double)mm) * 2.220446049250313e-16;
+  int cur = 0, sweeps = 0;
+  const int rounds = (P == 1) ? 1 : 2 * P - 1;
+  unsigned long long hflag = 0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
+    for (int r = 0; r < rounds; ++r) {
+      // 1. Gram (TN): M[p][q] = X_p[rows of split q]^T X_p[rows of split q]
+      GemmArgs g;
+      std::memset(&g, 0, sizeof(g));
+      g.A = G[cur]; g.B = G[cur]; g.C = Mpart; g.M = J2; g.N = J2; g.lda = mm; g.ldb = mm; g.ldc = J2;
+      g.batch = P * Q; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = 1; g.transB = 0;
+      g.tabA = t_gramA; g.tabB = t_gramA; g.tabC = t_gramC; g.tabs_even = kq_even;
+      g.K = kq;
+      if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+      // 2. eigen-decomposition of each 64x64 Gram matrix
+      hipLaunchKernelGGL(jacobi_eig_kernel, dim3(P), dim3(256), 0, s, Mpart, Q, Wm, tol, flag);
+      // 3. updates into next round's slots
+      GemmArgs u;
+      std::memset(&u, 0, sizeof(u));
+      u.B = Wm; u.N = JB; u.K = J2; u.ldb = J2; u.batch = 2 * P; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
+      u.tabB = t_updB; u.tabs_even = kq_even;
+      u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G; u.tabC = t_updC_G;
+      if ((e = gemm_f64(u, s)) != hipSuccess) return e;
+      u.A = V[cur]; u.C = V[cur ^ 1]; u.M = nn; u.lda = nn; u.ldc = nn; u.tabA = t_updA_V; u.tabC = t_updC_V;
+      if ((e = gemm_f64(u, s)) != hipSuccess) return e;
+      cur ^= 1;
+    }
+    ++sweeps;
+    if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    double mx;
+    std::memcpy(&mx, &hflag, sizeof(double));
+    if (mx <= tol) break;
+  }
+  if (sweeps_out) *sweeps_out = sweeps;
+
+  // singular values, sorting, truncation (host)
+  hipLaunchKernelGGL(colnorm2_kernel, dim3(npad), dim3(256), 0, s, G[cur], mm, mm, sigma2);
+  std::vector<double> hs(npad);
+  if ((e = hipMemcpyAsync(hs.data(), sigma2, sizeof(double) * npad, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+  std::vector<int> perm(npad);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return hs[a] > hs[b]; });
+  std::vector<double> sv(kmax), sc(kmax);
+  double tot2 = 0.0;
+  for (int i = 0; i < kmax; ++i) { sv[i] = std::sqrt(std::max(hs[perm[i]], 0.0)); tot2 += sv[i] * sv[i]; }
+  int k = kmax;
+  if (max_keep > 0 && max_keep < k) k = max_keep;
+  if (trunc_err > 0.0) {
+    // drop the tail while ||dropped||_2 <= trunc_err * ||S||_2   (TensorKit truncerr, p = 2)
+    double tail2 = 0.0;
+    for (int i = k; i < kmax; ++i) tail2 += sv[i] * sv[i];
+    while (k > 1 && tail2 + sv[k - 1] * sv[k - 1] <= trunc_err * trunc_err * tot2) { tail2 += sv[k - 1] * sv[k - 1]; --k; }
+  }
+  double disc2 = 0.0;
+  for (int i = k; i < kmax; ++i) disc2 += sv[i] * sv[i];
+  *kept = k;
+  *disc_norm = std::sqrt(disc2);
+  for (int i = 0; i < kmax; ++i) sc[i] = sv[i] > 0.0 ? 1.0 / sv[i] : 0.0;
+  if ((e = hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(scale, sc.data(), sizeof(double) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(S, sv.data(), sizeof(double) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+  if (!pl.transposed) {
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, G[cur], mm, m, d_perm, scale, kmax, U, ldu, 0);
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, V[cur], nn, n, d_perm, (const double*)nullptr,
+                       kmax, Vh, ldv, 1);
+  } else {   // theta^T = G V^T  ->  theta = V (G)^T :  U = V-part, Vh = (G diag(1/sigma))^T
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, V[cur], nn, m, d_perm, (const double*)nullptr,
+                       kmax, U, ldu, 0);
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, G[cur], mm, n, d_perm, scale, kmax, Vh, ldv, 1);
+  }
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;   // perm/sc/sv are host temporaries
+  return hipGetLastError();
+}
+
+}  // namespace mpsk

@@ -1,0 +1,51 @@
+"""Effective-Hamiltonian ("derivative") operators, src/algorithms/derivatives.jl:6-71.
+Same names and call convention as the reference: `h = ddAC(pos, psi, H, envs); y = h(x)` /
+`h * x`; every application is ONE call into libmpsk (mpsk_dAC / mpsk_dC / mpsk_dAC2)."""
+from __future__ import annotations
+
+from .backend import DTensor
+
+
+class MPO_ddC:  # MPO_∂∂C  derivatives.jl:6-9
+    def __init__(self, be, leftenv, rightenv):
+        self.be, self.leftenv, self.rightenv = be, leftenv, rightenv
+
+    def __call__(self, x: DTensor, out: DTensor = None):
+        return self.be.dC(self.leftenv, self.rightenv, x, out=out)
+
+    __mul__ = __call__
+
+
+class MPO_ddAC:  # MPO_∂∂AC  derivatives.jl:11-15
+    def __init__(self, be, o, leftenv, rightenv):
+        self.be, self.o, self.leftenv, self.rightenv = be, o, leftenv, rightenv
+
+    def __call__(self, x: DTensor, out: DTensor = None):
+        return self.be.dAC(self.o, self.leftenv, self.rightenv, x, out=out)
+
+    __mul__ = __call__
+
+
+class MPO_ddAC2:  # MPO_∂∂AC2  derivatives.jl:17-22
+    def __init__(self, be, o1, o2, leftenv, rightenv):
+        self.be, self.o1, self.o2, self.leftenv, self.rightenv = be, o1, o2, leftenv, rightenv
+
+    def __call__(self, x: DTensor, out: DTensor = None):
+        return self.be.dAC2(self.o1, self.o2, self.leftenv, self.rightenv, x, out=out)
+
+    __mul__ = __call__
+
+
+def ddC(pos, psi, H, envs):  # ∂∂C  derivatives.jl:34-36
+    return MPO_ddC(psi.be, envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi))
+
+
+def ddAC(pos, psi, H, envs):  # ∂∂AC  derivatives.jl:44-46
+    opp = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
+    return MPO_ddAC(psi.be, opp, envs.leftenv(pos, psi), envs.rightenv(pos, psi))
+
+
+def ddAC2(pos, psi, H, envs):  # ∂∂AC2  derivatives.jl:55-58
+    o1 = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
+    o2 = envs.opp[pos + 1] if hasattr(envs, "opp") else H[pos + 1]
+    return MPO_ddAC2(psi.be, o1, o2, envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi))

@@ -1,0 +1,163 @@
+"""Host-side Krylov solvers on DEVICE vectors (the KrylovKit role in the reference:
+src/algorithms/fixedpoint.jl:9-30, mpohaminfenv.jl:95).  The loop stays on the host, every
+matvec is one call into libmpsk, and the Gram-Schmidt step is the fused multi-dot / multi-axpy
+pair `mpsk_vgs_step` (coefficients never leave the device between the two kernels).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .backend import Backend, DTensor
+
+
+class KrylovWorkspace:
+    """Reusable pool of device vectors so that an eigsolve allocates nothing after warm-up."""
+
+    def __init__(self, be: Backend):
+        self.be = be
+        self.pool = {}
+
+    def get(self, shape, n):
+        key = tuple(shape)
+        lst = self.pool.setdefault(key, [])
+        while len(lst) < n:
+            lst.append(self.be.empty(*key))
+        return lst[:n]
+
+
+def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
+                fixed_matvecs=None, ws: KrylovWorkspace | None = None):
+    """Smallest-real eigenpair of a Hermitian operator: restarted Lanczos/Arnoldi with twice-iterated
+    classical Gram-Schmidt and an 'eager' convergence test each step (defaults.jl:33:
+    Arnoldi(; tol, maxiter, eager=true)).  matvec(x: DTensor, out: DTensor) -> out.
+    Returns (lambda, vec, n_matvecs, residual)."""
+    ws = KrylovWorkspace(be) if ws is None else ws
+    shape = x0.shape
+    vecs = ws.get(shape, krylovdim + 2)
+    V, ritz = vecs[:krylovdim + 1], vecs[krylovdim + 1]
+    nmv, lam, res = 0, 0.0, np.inf
+    start = x0
+    for _restart in range(maxiter):
+        nrm = be.norm(start)
+        be.axpby(1.0 / nrm, start, 0.0, V[0])
+        Hm = np.zeros((krylovdim + 1, krylovdim))
+        k, conv = 0, False
+        s = None
+        while k < krylovdim:
+            w = V[k + 1]
+            matvec(V[k], w)
+            nmv += 1
+            for _ in range(2):
+                Hm[:k + 1, k] += be.gs_step(V[:k + 1], w)
+            beta = be.norm(w)
+            Hm[k + 1, k] = beta
+            k += 1
+            Hk = Hm[:k, :k]
+            ev, S = np.linalg.eigh((Hk + Hk.T) / 2)
+            lam, s = ev[0], S[:, 0]
+            res = abs(beta * s[-1])
+            done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
+            if (fixed_matvecs is None and res < tol) or beta < 1e-300 or done_fixed:
+                conv = True
+                break
+            if k < krylovdim:
+                be.scal(1.0 / beta, w)
+        be.lincomb(V[:k], s, out=ritz)
+        start = ritz
+        if conv:
+            break
+    out = be.empty(*shape)
+    nrm = be.norm(ritz)
+    be.axpby(1.0 / nrm, ritz, 0.0, out)
+    return lam, out, nmv, res
+
+
+def eigsolve_lm_real(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
+                     ws: KrylovWorkspace | None = None):
+    """Dominant (largest-magnitude) eigenpair of a real non-symmetric operator whose dominant
+    eigenvector is real (transfer matrices: ortho.jl:184,241).  Restarted Arnoldi."""
+    ws = KrylovWorkspace(be) if ws is None else ws
+    shape = x0.shape
+    vecs = ws.get(shape, krylovdim + 2)
+    V, ritz = vecs[:krylovdim + 1], vecs[krylovdim + 1]
+    lam = 0.0
+    start = x0
+    for _restart in range(maxiter):
+        nrm = be.norm(start)
+        be.axpby(1.0 / nrm, start, 0.0, V[0])
+        Hm = np.zeros((krylovdim + 1, krylovdim))
+        k, conv = 0, False
+        s = None
+        while k < krylovdim:
+            w = V[k + 1]
+            matvec(V[k], w)
+            for _ in range(2):
+                Hm[:k + 1, k] += be.gs_step(V[:k + 1], w)
+            beta = be.norm(w)
+            Hm[k + 1, k] = beta
+            k += 1
+            ev, S = np.linalg.eig(Hm[:k, :k])
+            idx = int(np.argmax(np.abs(ev)))
+            lam, sv = ev[idx], S[:, idx]
+            res = abs(beta * sv[-1])
+            ph = sv[np.argmax(np.abs(sv))]
+            s = np.real(sv * np.conj(ph) / abs(ph))
+            if res < tol or beta < 1e-300:
+                conv = True
+                break
+            if k < krylovdim:
+                be.scal(1.0 / beta, w)
+        be.lincomb(V[:k], s, out=ritz)
+        start = ritz
+        if conv:
+            break
+    out = be.empty(*shape)
+    nrm = be.norm(ritz)
+    be.axpby(1.0 / nrm, ritz, 0.0, out)
+    return float(np.real(lam)), out
+
+
+def gmres(be: Backend, matvec, b: DTensor, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
+          ws: KrylovWorkspace | None = None):
+    """Restarted GMRES for matvec(x) = b on device vectors (KrylovKit.linsolve stand-in,
+    mpohaminfenv.jl:95,113,146,164).  Returns x (new DTensor)."""
+    ws = KrylovWorkspace(be) if ws is None else ws
+    shape = b.shape
+    vecs = ws.get(shape, krylovdim + 3)
+    V, r, tmp = vecs[:krylovdim + 1], vecs[krylovdim + 1], vecs[krylovdim + 2]
+    x = be.copy(x0)
+    bnorm = be.norm(b)
+    if bnorm == 0:
+        return be.zeros(*shape)
+    res = np.inf
+    for _ in range(maxiter):
+        matvec(x, tmp)
+        be.axpby(1.0, b, 0.0, r)
+        be.axpby(-1.0, tmp, 1.0, r)
+        beta = be.norm(r)
+        if beta <= tol:
+            break
+        be.axpby(1.0 / beta, r, 0.0, V[0])
+        Hm = np.zeros((krylovdim + 1, krylovdim))
+        k, y = 0, None
+        while k < krylovdim:
+            w = V[k + 1]
+            matvec(V[k], w)
+            for _ in range(2):
+                Hm[:k + 1, k] += be.gs_step(V[:k + 1], w)
+            hn = be.norm(w)
+            Hm[k + 1, k] = hn
+            k += 1
+            e1 = np.zeros(k + 1)
+            e1[0] = beta
+            y, *_ = np.linalg.lstsq(Hm[:k + 1, :k], e1, rcond=None)
+            res = np.linalg.norm(Hm[:k + 1, :k] @ y - e1)
+            if res <= tol or hn < 1e-300:
+                break
+            if k < krylovdim:
+                be.scal(1.0 / hn, w)
+        be.lincomb(V[:k], y, out=tmp)
+        be.axpby(1.0, tmp, 1.0, x)
+        if res <= tol:
+            break
+    return x

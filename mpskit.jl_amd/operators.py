@@ -1,0 +1,149 @@
+"""MPOHamiltonian / SparseMPOSlice on the device side (src/operators/mpohamiltonian.jl:8-31,
+sparsempo/sparseslice.jl:13-106 of the reference).  The container logic is host-only (no flops);
+each distinct slice owns one `mpsk_mposlice` handle.  Model builders mirror the toy Hamiltonians
+of test/setup.jl:38-65 and docs/src/man/operators.md:52-78."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .backend import Backend, DeviceMPOSlice, default_backend
+
+
+class MPOHamiltonian:
+    """Periodic list of block-sparse slices with H[.][1,1] = 1 and H[.][odim,odim] = 1
+    (mpohamiltonian.jl:8-31).  `data[site]` = dict {(i, j): scalar | d x d | [chi_i, d, d, chi_j]}."""
+
+    def __init__(self, data, d=None, chis=None, be: Backend | None = None):
+        self.be = default_backend() if be is None else be
+        if isinstance(data, dict):
+            data = [data]
+        self.period = len(data)
+        self.odim = 1 + max(max(i, j) for blk in data for (i, j) in blk)
+        odim = self.odim
+        # infer d and the level dimensions chi from the blocks
+        if d is None:
+            for blk in data:
+                for v in blk.values():
+                    if not np.isscalar(v):
+                        a = np.asarray(v)
+                        d = a.shape[0] if a.ndim == 2 else a.shape[1]
+                        break
+                if d is not None:
+                    break
+        if d is None:
+            raise ValueError("physical dimension cannot be inferred from scalar-only blocks; pass d=")
+        self.d = int(d)
+        if chis is None:
+            chis = [[1] * odim for _ in range(self.period + 1)]
+            for s, blk in enumerate(data):
+                for (i, j), v in blk.items():
+                    if not np.isscalar(v) and np.asarray(v).ndim == 4:
+                        a = np.asarray(v)
+                        chis[s][i] = a.shape[0]
+                        chis[s + 1][j] = a.shape[3]
+            for i in range(odim):  # periodic closure
+                m = max(chis[0][i], chis[self.period][i])
+                chis[0][i] = chis[self.period][i] = m
+        self.chis = chis
+        self.slices = []
+        for s, blk in enumerate(data):
+            blocks = {}
+            for (i, j), v in blk.items():
+                if np.isscalar(v):
+                    if v != 0:
+                        blocks[(i, j)] = v
+                    continue
+                a = np.asarray(v)
+                if a.ndim == 2:
+                    a = a[None, :, :, None]
+                if np.abs(a).max() < 1e-14:                      # sparsempo.jl:122-132
+                    continue
+                if a.shape[0] == a.shape[3]:
+                    c = a[0, 0, 0, 0]
+                    ident = np.einsum("wv,ts->wtsv", np.eye(a.shape[0]), np.eye(self.d))
+                    if c != 0 and np.allclose(a, c * ident, rtol=0, atol=1e-14 * max(1.0, abs(c))):
+                        blocks[(i, j)] = 1.0 if abs(c - 1) < 1e-14 else c
+                        continue
+                blocks[(i, j)] = a
+            self.slices.append(DeviceMPOSlice(self.be, odim, self.d, chis[s], chis[s + 1], blocks))
+        self._energy_slices = {}
+
+    def __getitem__(self, i):
+        return self.slices[i % self.period]
+
+    def __len__(self):
+        return self.period
+
+    def isid(self, i):  # mpohamiltonian.jl:53-58
+        return all(s.isscal(i, i) and abs(s.blocks[(i, i)] - 1) < 1e-14 for s in self.slices)
+
+    def energy_slice(self, site):
+        """Slice holding only the blocks that enter the per-site energy of expval.jl:92-109
+        ((j == 1 and k != 1) or (k == odim and j != odim)), halved unless (j, k) == (1, odim);
+        <AC| dAC_E |AC> / ||AC||^2 is then the reference's ens[site]."""
+        key = site % self.period
+        if key not in self._energy_slices:
+            s = self.slices[key]
+            odim = self.odim
+            blocks = {}
+            for (j, k), v in s.blocks.items():
+                if not ((j == 0 and k != 0) or (k == odim - 1 and j != odim - 1)):
+                    continue
+                f = 1.0 if (j == 0 and k == odim - 1) else 0.5
+                blocks[(j, k)] = f * v if np.isscalar(v) else f * np.asarray(v)
+            self._energy_slices[key] = DeviceMPOSlice(self.be, odim, self.d, s.chil, s.chir, blocks)
+        return self._energy_slices[key]
+
+
+# ---- models -----------------------------------------------------------------------------------
+
+def spin_ops(spin=0.5):
+    d = int(round(2 * spin + 1))
+    m = spin - np.arange(d)
+    Sz = np.diag(m)
+    Sp = np.zeros((d, d))
+    for k in range(1, d):
+        Sp[k - 1, k] = math.sqrt(spin * (spin + 1) - m[k] * (m[k] + 1))
+    return Sz, Sp, Sp.T.copy()
+
+
+def heisenberg_XXX(spin=0.5, J=1.0, be=None):
+    """Real 5-level Heisenberg MPO: H = J sum Sz Sz + (S+ S- + S- S+)/2 (block pattern of
+    docs/src/man/operators.md:67-78)."""
+    Sz, Sp, Sm = spin_ops(spin)
+    return MPOHamiltonian({(0, 0): 1.0, (4, 4): 1.0, (0, 1): J * Sz, (1, 4): Sz, (0, 2): 0.5 * J * Sp,
+                           (2, 4): Sm, (0, 3): 0.5 * J * Sm, (3, 4): Sp}, be=be)
+
+
+def transverse_field_ising(J=1.0, g=1.0, be=None):
+    """H = -J sum Z Z - g sum X (Pauli), docs/src/man/operators.md:52-58."""
+    X = np.array([[0.0, 1], [1, 0]])
+    Z = np.array([[1.0, 0], [0, -1]])
+    return MPOHamiltonian({(0, 0): 1.0, (2, 2): 1.0, (0, 1): -J * Z, (1, 2): Z, (0, 2): -g * X}, be=be)
+
+
+def from_twosite(h2, tol=1e-12, be=None):
+    """MPOHamiltonian(h::TensorMap two-site): SVD split (mpohamiltonian.jl:16-31, utility.jl:42-54)."""
+    d = h2.shape[0]
+    M = np.transpose(h2, (0, 2, 1, 3)).reshape(d * d, d * d)
+    U, S, Vh = np.linalg.svd(M)
+    keep = S > tol
+    U, S, Vh = U[:, keep], S[keep], Vh[keep, :]
+    r = len(S)
+    A = (U * S).reshape(d, d, r)[None, :, :, :]
+    B = Vh.reshape(r, d, d)[:, :, :, None]
+    return MPOHamiltonian({(0, 0): 1.0, (0, 1): A, (1, 2): B, (2, 2): 1.0}, be=be)
+
+
+def hubbard(t=1.0, U=4.0, be=None):
+    """Spinful Hubbard chain via Jordan-Wigner, d = 4, 6 MPO levels (model of BASELINE config 4)."""
+    c = np.array([[0.0, 1], [0, 0]])
+    P = np.diag([1.0, -1.0])
+    I2 = np.eye(2)
+    cu, cd, F = np.kron(c, I2), np.kron(P, c), np.kron(P, P)
+    nu, nd = cu.T @ cu, cd.T @ cd
+    return MPOHamiltonian({(0, 0): 1.0, (5, 5): 1.0, (0, 5): U * (nu @ nd),
+                           (0, 1): -t * (cu.T @ F), (1, 5): cu, (0, 2): t * (cu @ F), (2, 5): cu.T,
+                           (0, 3): -t * (cd.T @ F), (3, 5): cd, (0, 4): t * (cd @ F), (4, 5): cd.T}, be=be)

@@ -1,0 +1,131 @@
+"""End-to-end parity of the drivers (DMRG / DMRG2 / VUMPS on the HIP path) against the oracle,
+exact diagonalisation and the energies recorded in the reference's docs.  Bar (north star):
+ground-state energies within 1e-10 relative of the CPU path."""
+import numpy as np
+import pytest
+
+import mpskit_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+ETOL = 1e-10
+
+
+def _mk():
+    import mpskit_jl_amd as mk
+    return mk
+
+
+def test_gauge_identities_and_state_machine(be):
+    """test/states.jl:25-28 : AC = AL*CR = CR*AR on every site, norm = 1."""
+    mk = _mk()
+    rng = np.random.default_rng(1)
+    psi = mk.FiniteMPS.random(8, 2, 12, rng, be=be)
+    for i in range(8):
+        ac = be.download(psi.AC(i))
+        al, ar = be.download(psi.AL(i)), be.download(psi.AR(i))
+        cr, cl = be.download(psi.CR(i)), be.download(psi.CR(i - 1))
+        assert np.abs(np.einsum("asb,bk->ask", al, cr) - ac).max() < 1e-13
+        assert np.abs(np.einsum("ka,asb->ksb", cl, ar) - ac).max() < 1e-13
+        assert np.abs(np.einsum("asb,asc->bc", al, al) - np.eye(al.shape[2])).max() < 1e-13
+        assert np.abs(np.einsum("asb,csb->ac", ar, ar) - np.eye(ar.shape[0])).max() < 1e-13
+    assert abs(psi.norm() - 1) < 1e-13
+    # same inputs -> same canonical form as the oracle's state machine
+    rng = np.random.default_rng(2)
+    As = [rng.random((1, 2, 2)), rng.random((2, 2, 4)), rng.random((4, 2, 2)), rng.random((2, 2, 1))]
+    pg, po = mk.FiniteMPS(As, be=be), mo.FiniteMPS(As)
+    for i in range(4):
+        assert np.abs(be.download(pg.AC(i)) - po.AC(i)).max() < 1e-13
+        assert np.abs(be.download(pg.AR(i)) - po.AR(i)).max() < 1e-12
+
+
+def test_derivative_linearity(be):
+    """test/operators.jl:207-225 : dd(H1 + H2) x == ddH1 x + ddH2 x (here via the block sum)."""
+    mk = _mk()
+    rng = np.random.default_rng(3)
+    D, d = 24, 2
+    b1 = {(0, 0): 1.0, (2, 2): 1.0, (0, 1): rng.standard_normal((d, d)), (1, 2): rng.standard_normal((d, d))}
+    b2 = {(0, 0): 1.0, (2, 2): 1.0, (0, 2): rng.standard_normal((d, d))}
+    bsum = dict(b1)
+    bsum[(0, 2)] = b2[(0, 2)]
+    mksl = lambda b: be.mposlice(3, d, [1] * 3, [1] * 3, {k: (v if np.isscalar(v) else v[None, :, :, None]) for k, v in b.items()})
+    GL = be.upload_env([rng.standard_normal((D, 1, D)) for _ in range(3)])
+    GR = be.upload_env([rng.standard_normal((D, 1, D)) for _ in range(3)])
+    x = be.upload(rng.standard_normal((D, d, D)))
+    y1, y2, ys = (be.download(be.dAC(mksl(b), GL, GR, x)) for b in (b1, b2, bsum))
+    # the identity blocks (0,0),(2,2) are counted twice in y1 + y2
+    bid = {(0, 0): 1.0, (2, 2): 1.0}
+    yid = be.download(be.dAC(mksl(bid), GL, GR, x))
+    assert np.abs(y1 + y2 - yid - ys).max() < 1e-11 * np.abs(ys).max()
+
+
+@pytest.mark.parametrize("model,L,D,d", [("heis", 10, 16, 2), ("tfi", 12, 12, 2), ("heis1", 6, 27, 3)])
+def test_dmrg_matches_oracle_and_ed(be, model, L, D, d):
+    mk = _mk()
+    if model == "heis":
+        Hg, Ho = mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)
+    elif model == "heis1":
+        Hg, Ho = mk.heisenberg_XXX(1.0, be=be), mo.heisenberg_mpo(1.0)
+    else:
+        Hg, Ho = mk.transverse_field_ising(1.0, 0.7, be=be), mo.tfi_mpo(1.0, 0.7)
+    rng = np.random.default_rng(11)
+    dims = mo.FiniteMPS.random(L, d, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.random((1 if i == 0 else dims[i - 1], d, dims[i])) for i in range(L)]
+    psig = mk.FiniteMPS(As, normalize=True, be=be)
+    psio = mo.FiniteMPS(As, normalize=True)
+    pg, eg, epsg = mk.find_groundstate(psig, Hg, mk.DMRG(tol=1e-10, maxiter=10))
+    po, eo, epso, logo = mo.dmrg(psio, Ho, tol=1e-10, maxiter=10)
+    Eg = float(np.sum(mk.expectation_value(pg, Hg, eg)))
+    Eo = logo[-1][1]
+    assert epsg < 1e-9 and epso < 1e-9
+    assert abs(Eg - Eo) <= ETOL * abs(Eo)
+    if d ** L <= 2 ** 13:
+        e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
+        assert Eg >= e0 - 1e-9 * abs(e0)
+
+
+def test_dmrg_reference_recorded_energy(be):
+    """docs/src/examples/quantum1d/3.ising-dqpt/index.md:34-48 : TFI (|g| = 0.5) OBC L = 20 D = 10,
+    E = -20.40021786703 after 5 sweeps of the reference's DMRG."""
+    mk = _mk()
+    H = mk.transverse_field_ising(1.0, 0.5, be=be)
+    psi = mk.FiniteMPS.random(20, 2, 10, np.random.default_rng(5), be=be)
+    p, e, eps = mk.find_groundstate(psi, H, mk.DMRG(tol=1e-9, maxiter=10))
+    E = float(np.sum(mk.expectation_value(p, H, e)))
+    assert abs(E - (-20.40021786703)) < 2e-11 * 20.4 + 5e-11
+
+
+def test_dmrg2_matches_oracle(be):
+    mk = _mk()
+    L, D = 8, 16
+    Hg, Ho = mk.hubbard(1.0, 4.0, be=be), mo.hubbard_mpo(1.0, 4.0)
+    rng = np.random.default_rng(21)
+    dims = mo.FiniteMPS.random(L, 4, 8, np.random.default_rng(0)).bond_dims()
+    As = [rng.random((1 if i == 0 else dims[i - 1], 4, dims[i])) for i in range(L)]
+    pg, eg, epsg = mk.find_groundstate(mk.FiniteMPS(As, normalize=True, be=be), Hg,
+                                       mk.DMRG2(tol=1e-9, maxiter=6, trunc_dim=D))
+    po, eo, epso, logo = mo.dmrg2(mo.FiniteMPS(As, normalize=True), Ho, truncdim=D, tol=1e-9, maxiter=6)
+    Eg = float(np.sum(mk.expectation_value(pg, Hg, eg)))
+    assert max(pg.bond_dims()) <= D
+    assert abs(Eg - logo[-1][1]) <= 1e-8 * abs(Eg)      # truncated two-site sweeps: variational plateau
+    # with no effective truncation the energies agree to the parity bar
+    pg, eg, _ = mk.find_groundstate(mk.FiniteMPS(As, normalize=True, be=be), Hg,
+                                    mk.DMRG2(tol=1e-10, maxiter=6, trunc_dim=256))
+    po, eo, _, logo = mo.dmrg2(mo.FiniteMPS(As, normalize=True), Ho, truncdim=256, tol=1e-10, maxiter=6)
+    Eg = float(np.sum(mk.expectation_value(pg, Hg, eg)))
+    assert abs(Eg - logo[-1][1]) <= ETOL * abs(Eg)
+
+
+def test_vumps_reference_recorded_energy(be):
+    """docs/src/examples/quantum1d/3.ising-dqpt/index.md:105-118 : infinite TFI (|g| = 0.5), D = 10,
+    e = -1.063544409973 ; and parity with the oracle VUMPS."""
+    mk = _mk()
+    H = mk.transverse_field_ising(1.0, 0.5, be=be)
+    A = np.random.default_rng(9).random((10, 2, 10))
+    psi = mk.InfiniteMPS.from_tensors([A], be=be)
+    p, e, eps = mk.find_groundstate(psi, H, mk.VUMPS(tol=1e-10, maxiter=40))
+    E = float(np.sum(mk.expectation_value(p, H, e)))
+    assert eps < 1e-9
+    assert abs(E - (-1.063544409973)) < 2e-12
+    po, eo, epso, logo = mo.vumps(mo.InfiniteMPS.from_tensors([A]), mo.tfi_mpo(1.0, 0.5), tol=1e-10, maxiter=40)
+    assert abs(E - logo[-1][1]) <= ETOL * abs(E)

@@ -156,3 +156,97 @@ def test_vectors(be):
         be.axpby(2.0, dxs[0], -0.5, z)
         be.scal(3.0, z)
         assert relerr(be.download(z), 3 * (2 * xs[0] - 0.5 * sum((i + 1) * x for i, x in enumerate(xs)))) < 1e-13
+
+
+QR_CASES = [(8, 4), (4, 4), (64, 64), (100, 37), (33, 1), (768, 256), (1030, 515), (2048, 1024), (4096, 1024)]
+
+
+@pytest.mark.parametrize("m,n", QR_CASES)
+def test_qrpos(be, m, n):
+    rng = np.random.default_rng(m * 31 + n)
+    A = rng.random((m, n))          # uniform[0,1) like the reference's `rand`
+    Q, R = be.qrpos(be.upload(A))
+    Q, R = be.download(Q), be.download(R)
+    Qr, Rr = mo.qrpos(A)
+    assert np.all(np.diag(R) > 0)
+    assert np.abs(np.tril(R, -1)).max(initial=0.0) == 0.0
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-13 * np.sqrt(m)
+    assert relerr(Q @ R, A) < 1e-12
+    assert relerr(R, Rr) < 1e-11 and relerr(Q, Qr) < 1e-10
+
+
+def test_qrpos_illconditioned_and_rank_deficient(be):
+    rng = np.random.default_rng(7)
+    m, n = 512, 256
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.logspace(0, -14, n)     # Schmidt-like spectrum, cond = 1e14
+    A = (U * s) @ V.T
+    Q, R = be.qrpos(be.upload(A))
+    Q, R = be.download(Q), be.download(R)
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-12
+    assert relerr(Q @ R, A) < 1e-13
+    # exactly rank deficient: zero columns + duplicated column
+    A2 = rng.random((96, 48))
+    A2[:, 5] = 0.0
+    A2[:, 9] = A2[:, 3]
+    Q, R = be.qrpos(be.upload(A2))
+    Q, R = be.download(Q), be.download(R)
+    assert np.all(np.isfinite(Q)) and np.all(np.isfinite(R))
+    assert relerr(Q @ R, A2) < 1e-13
+    assert np.abs(Q.T @ Q - np.eye(48)).max() < 1e-12
+
+
+@pytest.mark.parametrize("m,n", [(4, 8), (64, 64), (37, 100), (256, 768), (1024, 2048)])
+def test_lqpos(be, m, n):
+    rng = np.random.default_rng(m * 17 + n)
+    A = rng.random((m, n))
+    L, Q = be.lqpos(be.upload(A))
+    L, Q = be.download(L), be.download(Q)
+    Lr, Qr = mo.lqpos(A)
+    assert np.all(np.diag(L) > 0) and np.abs(np.triu(L, 1)).max(initial=0.0) == 0.0
+    assert np.abs(Q @ Q.T - np.eye(m)).max() < 1e-13 * np.sqrt(n)
+    assert relerr(L @ Q, A) < 1e-13
+    assert relerr(L, Lr) < 1e-11 and relerr(Q, Qr) < 1e-10
+
+
+@pytest.mark.parametrize("m,n", [(4, 4), (6, 10), (64, 64), (100, 37), (37, 100), (256, 256), (768, 768),
+                                 (2048, 1024)])
+def test_tsvd_full(be, m, n):
+    rng = np.random.default_rng(m * 13 + n)
+    A = rng.random((m, n))
+    U, S, Vh, kept, disc = be.tsvd(be.upload(A))
+    U, S, Vh = be.download(U), be.download(S), be.download(Vh)
+    k = min(m, n)
+    assert kept == k and disc == 0.0
+    Sr = np.linalg.svd(A, compute_uv=False)
+    assert np.all(np.diff(S) <= 0)
+    assert np.abs(S - Sr).max() < 1e-12 * Sr[0]
+    assert np.abs(U.T @ U - np.eye(k)).max() < 1e-12
+    assert np.abs(Vh @ Vh.T - np.eye(k)).max() < 1e-12
+    assert relerr((U * S) @ Vh, A) < 1e-12
+
+
+def test_tsvd_truncation_and_small_singular_values(be):
+    rng = np.random.default_rng(99)
+    m = n = 192
+    Uo, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    Vo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.logspace(0, -12, n)                    # Schmidt-like spectrum
+    A = (Uo * s) @ Vo.T
+    # truncdim
+    U, S, Vh, kept, disc = be.tsvd(be.upload(A), max_keep=40)
+    S = be.download(S)
+    assert kept == 40
+    # backward-stable accuracy: absolute error ~ eps * sigma_max for EVERY singular value
+    # (the mixing V makes the small ones ill-determined relatively; LAPACK gives the same)
+    assert np.abs(S[:n] - s).max() < 1e-14
+    assert abs(disc - np.linalg.norm(s[40:])) < 1e-14
+    U, Vh = be.download(U)[:, :kept], be.download(Vh)[:kept]
+    assert relerr((U * S[:kept]) @ Vh, (Uo[:, :40] * s[:40]) @ Vo[:, :40].T) < 1e-12
+    # truncerr (TensorKit semantics: discarded 2-norm <= eps * total 2-norm), cf. oracle tsvd
+    eps = 1e-6
+    _, S2, _, kept2, disc2 = be.tsvd(be.upload(A), trunc_err=eps)
+    _, So, _, erro = mo.tsvd(A.reshape(m, 1, n, 1), truncerr=eps)
+    assert kept2 == len(So)
+    assert abs(disc2 - erro) < 1e-13
