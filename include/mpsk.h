@@ -52,8 +52,17 @@ int mpsk_ctx_destroy(mpsk_ctx* ctx);
 int mpsk_ctx_set_stream(mpsk_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = default */
 int mpsk_ctx_synchronize(mpsk_ctx* ctx);
 int mpsk_ctx_workspace_reserve(mpsk_ctx* ctx, size_t bytes);   /* pre-size the private workspace */
+/* QRpos algorithm: 0 auto (shifted CholeskyQR3 on the GEMM core, Householder fallback when the device
+ * flags an ill-conditioned / rank-deficient input), 1 Householder only, 2 CholeskyQR3 only (error on flag) */
+int mpsk_ctx_set_qr_mode(mpsk_ctx* ctx, int mode);
+int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallback);
 /* tile override for benchmarking the GEMM core (0,0 restores the heuristic) */
 int mpsk_ctx_force_tile(mpsk_ctx* ctx, int bm, int bn);
+
+/* HIP-event profile of the matvec-stage GEMM launches (the dominant kernel, dac_gemm_f64_kernel):
+ * enable, run, then read a JSON summary [{kernel, launches, total_ms, avg_ms, flops}] (synchronises). */
+int mpsk_prof_enable(mpsk_ctx* ctx, int on);
+int mpsk_prof_summary(mpsk_ctx* ctx, char* buf, size_t buflen);
 
 /* ---- memory helpers (optional) ------------------------------------------------------------ */
 int mpsk_malloc(mpsk_ctx* ctx, size_t bytes, void** dptr);

@@ -32,6 +32,10 @@ SIGNATURES = {
     "mpsk_ctx_synchronize": [C.c_void_p],
     "mpsk_ctx_workspace_reserve": [C.c_void_p, C.c_size_t],
     "mpsk_ctx_force_tile": [C.c_void_p, C.c_int, C.c_int],
+    "mpsk_ctx_set_qr_mode": [C.c_void_p, C.c_int],
+    "mpsk_ctx_qr_stats": [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)],
+    "mpsk_prof_enable": [C.c_void_p, C.c_int],
+    "mpsk_prof_summary": [C.c_void_p, C.c_char_p, C.c_size_t],
     "mpsk_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
     "mpsk_free": [C.c_void_p, C.c_void_p],
     "mpsk_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
@@ -82,6 +86,14 @@ def load():
         raise MpskError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64 / libhsa-runtime64.  If
+    # libmpsk were loaded first it would bind the system copies and the two ROCr instances would
+    # fight over the device ("no ROCm-capable device is detected").  Importing torch first makes
+    # libmpsk's DT_NEEDED libamdhip64.so resolve to the already-loaded runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -77,14 +77,15 @@ def fixedpoint(be, A, x0, alg: Arnoldi, ws=None):
 
 # ---- measurements ------------------------------------------------------------------------------
 
-def calc_galerkin(psi, pos, envs):
-    """|| (1 - AL AL^dag) normalize(H_AC AC) ||   (toolbox.jl:17-22)."""
+def calc_galerkin(psi, pos, envs, h=None):
+    """|| (1 - AL AL^dag) normalize(H_AC AC) ||   (toolbox.jl:17-22).
+    h: the site's effective Hamiltonian if the caller already built it (same operator)."""
     be = psi.be
     if isinstance(psi, FiniteMPS):
         ac, al = psi.AC(pos), psi.AL(pos)
-        h = ddAC(pos, psi, envs.H, envs)
     else:
         ac, al = psi.AC[pos], psi.AL[pos]
+    if h is None:
         h = ddAC(pos, psi, envs.H, envs)
     g = h(ac)
     be.scal(1.0 / be.norm(g), g)
@@ -142,6 +143,24 @@ def find_groundstate(psi, H, alg=None, envs=None):
     raise TypeError(f"unknown algorithm {alg!r}")
 
 
+def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None, wrap=None):
+    """One full DMRG sweep, pos in [1:L-1; L:-1:2] (dmrg.jl:33-38): per site one eigsolve with the
+    effective Hamiltonian, one galerkin evaluation, and the lazy gauge / environment updates that
+    the next site triggers.  Returns the per-site galerkin errors.
+    wrap: optional h -> h' (dist.shard_wrapper: bond-sharded multi-GPU matvec)."""
+    be = psi.be
+    L = len(psi)
+    eps_s = [0.0] * L
+    for pos in list(range(0, L - 1)) + list(range(L - 1, 0, -1)):
+        h = ddAC(pos, psi, H, envs)
+        if wrap is not None:
+            h = wrap(h)
+        _, vec = fixedpoint(be, h, psi.AC(pos), eigalg, ws)
+        eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs, h=h))
+        psi.set_AC(pos, vec)
+    return eps_s
+
+
 def _dmrg(psi, H, alg: DMRG, envs=None):  # dmrg.jl:22-55
     be = psi.be
     envs = FinEnv(psi, H) if envs is None else envs
@@ -152,12 +171,7 @@ def _dmrg(psi, H, alg: DMRG, envs=None):  # dmrg.jl:22-55
     t0 = time.time()
     history = []
     for it in range(1, alg.maxiter + 1):
-        eps_s = [0.0] * L
-        for pos in list(range(0, L - 1)) + list(range(L - 1, 0, -1)):
-            h = ddAC(pos, psi, H, envs)
-            _, vec = fixedpoint(be, h, psi.AC(pos), alg.eigalg, ws)
-            eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs))
-            psi.set_AC(pos, vec)
+        eps_s = dmrg_sweep(psi, H, envs, alg.eigalg, ws)
         eps = max(eps_s)
         if alg.finalize is not None:
             psi, envs = alg.finalize(it, psi, H, envs)

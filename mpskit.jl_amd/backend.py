@@ -75,6 +75,23 @@ class Backend:
     def synchronize(self):
         check(self.lib.mpsk_ctx_synchronize(self.ctx), "mpsk_ctx_synchronize")
 
+    def set_qr_mode(self, mode):
+        check(self.lib.mpsk_ctx_set_qr_mode(self.ctx, int(mode)), "mpsk_ctx_set_qr_mode")
+
+    def qr_stats(self):
+        a, b, f = C.c_long(), C.c_long(), C.c_long()
+        check(self.lib.mpsk_ctx_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(f)), "mpsk_ctx_qr_stats")
+        return {"cholqr3": a.value, "householder": b.value, "fallback": f.value}
+
+    def prof_enable(self, on=True):
+        check(self.lib.mpsk_prof_enable(self.ctx, int(on)), "mpsk_prof_enable")
+
+    def prof_summary(self):
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        check(self.lib.mpsk_prof_summary(self.ctx, buf, len(buf)), "mpsk_prof_summary")
+        return json.loads(buf.value.decode())
+
     # ---- memory ---------------------------------------------------------------------------
     def empty(self, *shape):
         torch = _torch()

@@ -44,6 +44,9 @@ struct mpsk_ctx {
   double* d_partial = nullptr;  // dot scratch
   double* h_scal = nullptr;     // pinned host mirror
   int last_svd_sweeps = 0;
+  int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
+  int* d_flag = nullptr;
+  long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0;
   std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
 };
 constexpr int MAXK = 256;
@@ -68,6 +71,7 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
   HIPCHK(hipMalloc(&c->d_scal, sizeof(double) * MAXK));
   HIPCHK(hipMalloc(&c->d_partial, sizeof(double) * MPSK_DOT_SCRATCH));
   HIPCHK(hipHostMalloc(&c->h_scal, sizeof(double) * MAXK, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&c->d_flag, 64));
   *out = c;
   return MPSK_OK;
 }
@@ -81,6 +85,7 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->d_scal) (void)hipFree(c->d_scal);
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->d_flag) (void)hipFree(c->d_flag);
   delete c;
   return MPSK_OK;
 }
@@ -115,6 +120,21 @@ int mpsk_ctx_force_tile(mpsk_ctx* c, int bm, int bn) {
   REQUIRE(c, "ctx is NULL");
   REQUIRE((bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)), "tile must be 64/128");
   gemm_force_tile(bm, bn);
+  return MPSK_OK;
+}
+
+// Event profile of the matvec-stage GEMM launches (kernel dac_gemm_f64_kernel): enable, run, then
+// read a JSON summary [{kernel, launches, total_ms, avg_ms, flops}] (device-synchronising).
+int mpsk_prof_enable(mpsk_ctx* c, int on) {
+  REQUIRE(c, "ctx is NULL");
+  gemm_prof_enable(on != 0);
+  return MPSK_OK;
+}
+int mpsk_prof_summary(mpsk_ctx* c, char* buf, size_t buflen) {
+  REQUIRE(c && buf && buflen > 0, "NULL argument");
+  std::string s = gemm_prof_summary();
+  if (s.size() + 1 > buflen) return fail(MPSK_ERR_INVALID, "mpsk_prof_summary: buffer too small");
+  std::memcpy(buf, s.c_str(), s.size() + 1);
   return MPSK_OK;
 }
 
@@ -287,6 +307,7 @@ int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const
   // stage 1: T1[w] = GL[w] * x     (batched over w)
   GemmArgs g1 = mk((const double*)GL, (const double*)x, T1, Dlo, d * Dr, Dl, Dlo, Dl, Dlo);
   g1.batch = Wl; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.tag = 1;
   HIPCHK(gemm_f64(g1, c->stream));
   // stage 2: T2[v][:,t,:] = sum_{w,s} O[w,t,s,v] T1[w][:,s,:]
   SlabIndex ix{d, 1 << 30, (int64_t)Dlo, (int64_t)slab, 0, (int64_t)Dlo * d};
@@ -296,6 +317,7 @@ int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const
   for (int v = 0; v < Wr; ++v) if (H->col_used[v]) { sa.push_back((int64_t)v * slab); sb.push_back((int64_t)v * Dr * Dr); }
   if (sa.empty()) { HIPCHK(zero_async(y, sizeof(double) * slab, c->stream)); return MPSK_OK; }
   GemmArgs g3 = mk(T2, (const double*)GR, (double*)y, Dlo * d, Dr, Dr, (int64_t)Dlo * d, Dr, (int64_t)Dlo * d);
+  g3.tag = 1;
   HIPCHK(gemm_segments(g3, sa, sb, c->stream));
   return MPSK_OK;
 }
@@ -309,10 +331,12 @@ int mpsk_dC(mpsk_ctx* c, int W, int Dlo, int Dl, int Dr, const void* GL, const v
   double* T1 = (double*)c->ws;
   GemmArgs g1 = mk((const double*)GL, (const double*)cm, T1, Dlo, Dr, Dl, Dlo, Dl, Dlo);
   g1.batch = W; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.tag = 1;
   HIPCHK(gemm_f64(g1, c->stream));
   std::vector<int64_t> sa, sb;
   for (int w = 0; w < W; ++w) { sa.push_back((int64_t)w * slab); sb.push_back((int64_t)w * Dr * Dr); }
   GemmArgs g3 = mk(T1, (const double*)GR, (double*)y, Dlo, Dr, Dr, Dlo, Dr, Dlo);
+  g3.tag = 1;
   HIPCHK(gemm_segments(g3, sa, sb, c->stream));
   return MPSK_OK;
 }
@@ -364,6 +388,7 @@ int mpsk_dAC2(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* H2, int
   if (int rc = pair_plan(c, H1, H2, &plan)) return rc;
   GemmArgs g1 = mk((const double*)GL, (const double*)x2, T1, Dlo, d1 * Dr * d2, Dl, Dlo, Dl, Dlo);
   g1.batch = Wl; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.tag = 1;
   HIPCHK(gemm_f64(g1, c->stream));
   SlabIndex ix{d1, d2, (int64_t)Dlo, (int64_t)plane, (int64_t)slab, (int64_t)Dlo * d1};
   HIPCHK(mix_apply(*plan, T1, ix, T2, ix, Dlo, Dr, c->stream));
@@ -371,6 +396,7 @@ int mpsk_dAC2(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* H2, int
   for (int v = 0; v < Wr; ++v) if (H2->col_used[v]) { sa.push_back((int64_t)v * slab); sb.push_back((int64_t)v * Dr * Dr); }
   if (sa.empty()) { HIPCHK(zero_async(y2, sizeof(double) * slab, c->stream)); return MPSK_OK; }
   GemmArgs g3 = mk(T2, (const double*)GR, (double*)y2, Dlo * d1, Dr, Dr, (int64_t)Dlo * d1, Dr, (int64_t)Dlo * d1);
+  g3.tag = 1;
   g3.batch = d2; g3.bsA = (int64_t)plane; g3.bsB = 0; g3.bsC = (int64_t)plane;
   HIPCHK(gemm_segments(g3, sa, sb, c->stream));
   return MPSK_OK;
@@ -442,16 +468,51 @@ int mpsk_regularize(mpsk_ctx* c, int W, int D1, int D2, void* v, const void* lve
   return MPSK_OK;
 }
 
+// QRpos dispatcher: CholeskyQR3 (GEMM-rich) for n > 64 with a Householder fallback when the device
+// flag reports a non-positive pivot / a Gram matrix far from the identity (rank-deficient input).
+static int qrpos_dispatch(mpsk_ctx* c, int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr,
+                          double* ws) {
+  std::string err;
+  if (c->qr_mode != 1 && n > 64) {
+    int flag = 0;
+    hipError_t e = cholqr3(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream);
+    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3: ") + hipGetErrorString(e));
+    if (flag == 0) { c->n_qr_chol++; return MPSK_OK; }
+    if (c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
+    c->n_qr_fallback++;
+  }
+  c->n_qr_house++;
+  hipError_t e = qrpos(m, n, A, lda, Q, ldq, R, ldr, ws, c->stream, &err);
+  if (e != hipSuccess) return fail(err.empty() ? MPSK_ERR_HIP : MPSK_ERR_INVALID, "qrpos: " + (err.empty() ? std::string(hipGetErrorString(e)) : err));
+  return MPSK_OK;
+}
+
+static size_t qr_ws_doubles(int m, int n) {
+  size_t a = qrpos_workspace_doubles(m, n), b = cholqr_workspace_doubles(m, n);
+  return a > b ? a : b;
+}
+
+int mpsk_ctx_set_qr_mode(mpsk_ctx* c, int mode) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (Householder) or 2 (CholeskyQR3 only)");
+  c->qr_mode = mode;
+  return MPSK_OK;
+}
+int mpsk_ctx_qr_stats(mpsk_ctx* c, long* n_chol, long* n_house, long* n_fallback) {
+  REQUIRE(c, "ctx is NULL");
+  if (n_chol) *n_chol = c->n_qr_chol;
+  if (n_house) *n_house = c->n_qr_house;
+  if (n_fallback) *n_fallback = c->n_qr_fallback;
+  return MPSK_OK;
+}
+
 int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
   REQUIRE(c && A && Q && R, "NULL argument");
   REQUIRE(m >= n && n > 0, "needs m >= n > 0");
   REQUIRE(lda >= m && ldq >= m && ldr >= n, "leading dimension too small");
   HIPCHK(hipSetDevice(c->device));
-  if (int rc = ensure_ws(c, sizeof(double) * qrpos_workspace_doubles(m, n))) return rc;
-  std::string err;
-  hipError_t e = qrpos(m, n, (const double*)A, lda, (double*)Q, ldq, (double*)R, ldr, (double*)c->ws, c->stream, &err);
-  if (e != hipSuccess) return fail(err.empty() ? MPSK_ERR_HIP : MPSK_ERR_INVALID, "mpsk_qrpos: " + (err.empty() ? std::string(hipGetErrorString(e)) : err));
-  return MPSK_OK;
+  if (int rc = ensure_ws(c, sizeof(double) * qr_ws_doubles(m, n))) return rc;
+  return qrpos_dispatch(c, m, n, (const double*)A, lda, (double*)Q, ldq, (double*)R, ldr, (double*)c->ws);
 }
 
 // LQ of A (m x n, m <= n) through the QR of A^T:  A^T = Qt Rt  ->  L = Rt^T, Q = Qt^T
@@ -460,7 +521,7 @@ int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int l
   REQUIRE(m <= n && m > 0, "needs 0 < m <= n");
   REQUIRE(lda >= m && ldq >= m && ldl >= m, "leading dimension too small");
   HIPCHK(hipSetDevice(c->device));
-  const size_t qws = qrpos_workspace_doubles(n, m);
+  const size_t qws = qr_ws_doubles(n, m);
   const size_t extra = (size_t)2 * n * m + (size_t)m * m;
   if (int rc = ensure_ws(c, sizeof(double) * (qws + extra))) return rc;
   double* At = (double*)c->ws;            // n x m
@@ -468,9 +529,7 @@ int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int l
   double* Rt = Qt + (size_t)n * m;        // m x m
   double* ws2 = Rt + (size_t)m * m;
   HIPCHK(transpose((const double*)A, lda, m, n, At, n, c->stream));
-  std::string err;
-  hipError_t e = qrpos(n, m, At, n, Qt, n, Rt, m, ws2, c->stream, &err);
-  if (e != hipSuccess) return fail(err.empty() ? MPSK_ERR_HIP : MPSK_ERR_INVALID, "mpsk_lqpos: " + (err.empty() ? std::string(hipGetErrorString(e)) : err));
+  if (int rc = qrpos_dispatch(c, n, m, At, n, Qt, n, Rt, m, ws2)) return rc;
   HIPCHK(transpose(Qt, n, n, m, (double*)Q, ldq, c->stream));
   HIPCHK(transpose(Rt, m, m, m, (double*)L, ldl, c->stream));
   return MPSK_OK;

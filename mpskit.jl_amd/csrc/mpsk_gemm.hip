@@ -15,6 +15,10 @@
 //     K-major  image [BMN][BK+2]    (row stride 144 B: 16 rows hit 16 distinct 16-B slots)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
 #include "mpsk_internal.h"
 
 namespace mpsk {
@@ -83,7 +87,7 @@ template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
 };
 
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile (2x2 waves)
   constexpr int TM = WTM / 16, TN = WTN / 16; // MFMA tiles per wave
   // A is "k-contiguous" when transposed, B is "k-contiguous" when NOT transposed
@@ -187,6 +191,58 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
 }
 
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
+  gemm_body<BM, BN, TA, TB, ALIGNED>(g);
+}
+
+// Same body under its own symbol for the two big GEMM stages of the effective-Hamiltonian matvecs
+// (dAC / dC / dAC2): rocprofv3 --stats and the in-library event profile then report the hot kernel
+// separately from the small gauge-step GEMMs.
+template <int BM, int BN, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_f64_kernel(GemmArgs g) {
+  gemm_body<BM, BN, false, false, ALIGNED>(g);
+}
+
+// ---- event profile of the tagged (matvec) launches ---------------------------------------------
+struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+void gemm_prof_enable(bool on) {
+  if (on && !g_prof_on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+  }
+  g_prof_on = on;
+}
+
+// JSON list of {kernel, launches, total_ms, avg_ms, flops}; synchronises the device.
+std::string gemm_prof_summary() {
+  (void)hipDeviceSynchronize();
+  struct Agg { long n = 0; double ms = 0, flops = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    char key[96];
+    snprintf(key, sizeof(key), "dac_gemm_f64_kernel<%d,%d,%s>", r.bm, r.bn, r.aligned ? "true" : "false");
+    Agg& a = agg[key];
+    a.n++; a.ms += ms; a.flops += r.flops;
+  }
+  std::string out = "[";
+  bool first = true;
+  for (auto& kv : agg) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"avg_ms\": %.6f, \"flops\": %.6e}",
+             first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.ms / kv.second.n, kv.second.flops);
+    out += buf;
+    first = false;
+  }
+  out += "]";
+  return out;
+}
+
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
 static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   using LA = TileLoader<BM, TA, ALIGNED>;
   using LB = TileLoader<BN, !TB, ALIGNED>;
@@ -201,6 +257,30 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   }
   const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
   dim3 grid(tilesM * tilesN, g.batch, 1);
+  if constexpr (!TA && !TB) {
+    if (g.tag == 1) {
+      auto dk = dac_gemm_f64_kernel<BM, BN, ALIGNED>;
+      static bool dattr = false;
+      if (!dattr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dk),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        dattr = true;
+      }
+      if (g_prof_on) {
+        ProfRec r;
+        r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED;
+        (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, s);
+        hipLaunchKernelGGL(dk, grid, dim3(NTHREADS), smem, s, g);
+        (void)hipEventRecord(r.e1, s);
+        g_prof.push_back(r);
+      } else {
+        hipLaunchKernelGGL(dk, grid, dim3(NTHREADS), smem, s, g);
+      }
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, s, g);
   return hipGetLastError();
 }
@@ -213,19 +293,14 @@ static hipError_t launch_tile(const GemmArgs& g, int bm, int bn, hipStream_t s) 
   return launch_cfg<64, 64, TA, TB, ALIGNED>(g, s);
 }
 
-// Tile choice: minimise the makespan estimate  ceil(tiles / slots) * tile_cost / efficiency.
-// 256 CUs; every CU runs at most 2 workgroups, each at half the MFMA rate, so the cost of a
-// round is proportional to the tile volume; smaller tiles have lower MFMA density.
+// Tile choice (measured on MI355X, tools/bench_dac.py): the largest tile that still yields >= 6
+// workgroups per CU wins (D = 2048: 128x128, 62 TF); below that, smaller tiles balance the 256 CUs
+// better and run 4 waves/SIMD (D = 1024: 64x64 53 TF vs 128x128 35 TF).
 static void choose_tile(int M, int N, int batch, int* bm, int* bn) {
-  const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-  const double eff[4] = {1.0, 0.97, 0.97, 0.93};
-  double best = 1e300;
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
   for (int c = 0; c < 4; ++c) {
-    int tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
-    double tiles = (double)tm * tn * batch;
-    double rounds = ceil(tiles / 256.0);
-    double cost = rounds * cand[c][0] * cand[c][1] / eff[c];
-    if (cost < best * 0.999) { best = cost; *bm = cand[c][0]; *bn = cand[c][1]; }
+    int64_t tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
+    if (tm * tn * batch >= 6 * 256 || c == 3) { *bm = cand[c][0]; *bn = cand[c][1]; return; }
   }
 }
 

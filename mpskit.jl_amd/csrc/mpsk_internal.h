@@ -26,11 +26,14 @@ struct GemmArgs {
   const int64_t* tabA;
   const int64_t* tabB;
   const int64_t* tabC;
+  int tag;                   // 1: matvec-stage launch (own kernel symbol + event profile)
   int tabs_even;             // caller guarantees every tabA/tabB entry is even (16-B aligned operands)
 };
 
 hipError_t gemm_f64(const GemmArgs& g, hipStream_t s);
 void gemm_force_tile(int bm, int bn);
+void gemm_prof_enable(bool on);
+std::string gemm_prof_summary();
 
 // ---- slab mixing:  out_slab[o][r,c] = sum_t coef[t] * in_slab[src[t]][r,c]  --------------------
 // A "slab" is an R x C column-major matrix view (ld, base offset) inside a larger tensor.  This
@@ -73,6 +76,9 @@ size_t qrpos_workspace_doubles(int m, int n);
 hipError_t qrpos(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                  hipStream_t s, std::string* err);
 
+size_t cholqr_workspace_doubles(int m, int n);
+hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
+                   int* d_flag, int* flag_out, hipStream_t s);
 size_t tsvd_workspace_bytes(int m, int n);
 hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
                 int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,

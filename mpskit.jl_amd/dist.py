@@ -1,0 +1,125 @@
+"""Multi-GPU: bond-index sharding of the effective-Hamiltonian matvec (partition B).
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).  The output bond
+index a' of  y[a',t,b'] = sum GL[w][a',a] x[a,s,b] O[w,t,s,v] GR[v][b,b']  is block-partitioned:
+rank p owns rows [p*D/P, (p+1)*D/P) of every left-environment slab, computes y[a'_p,:,:] with the
+SAME kernels (mpsk_dAC with Dlo = D/P: both GEMM stages shrink by 1/P) and ONE collective per
+matvec (all-gather of D*d*D/P doubles per rank) completes y on every rank; no reduction, so every
+rank holds bit-identical iterates and the replicated host-side Krylov loop stays in lock-step.
+Everything else of the sweep (gauge steps, environment updates) is replicated in this round
+("replicas" for those steps; DESIGN.md lists the fully sharded environment update as next).
+
+The partition / gather-layout logic is independent of the device plumbing so that it is covered
+by world_size-2 gloo tests on CPU (tests/test_dist_cpu.py) with a host stand-in for the plumbing.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class BondShard:
+    """Equal row blocks of the bond index [0, D) over `world` ranks (requires world | D)."""
+
+    def __init__(self, D: int, world: int, rank: int):
+        if D % world != 0:
+            raise ValueError(f"bond dimension {D} is not divisible by world size {world}")
+        self.D, self.world, self.rank = D, world, rank
+        self.block = D // world
+
+    @property
+    def lo(self):
+        return self.rank * self.block
+
+    @property
+    def hi(self):
+        return self.lo + self.block
+
+    @staticmethod
+    def shardable(D, world, min_block=64):
+        return world > 1 and D % world == 0 and D // world >= min_block
+
+
+class HostPlumbing:
+    """NumPy stand-in for the device plumbing (used by the CPU gloo tests only)."""
+
+    def __init__(self, local_dAC):
+        self._dAC = local_dAC
+
+    def row_block(self, env, lo, hi):          # env: ndarray (W, Dbra, Dket)
+        return np.ascontiguousarray(env[:, lo:hi, :])
+
+    def local_dAC(self, H, GLloc, GR, x):
+        return self._dAC(H, GLloc, GR, x)
+
+    def all_gather_rows(self, yloc, group, world):
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(yloc))
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        return np.concatenate([o.numpy() for o in outs], axis=0)
+
+
+class DevicePlumbing:
+    """Device implementation: copy2d row-block extraction, mpsk_dAC on the local block, RCCL
+    all-gather through torch.distributed on the ctx stream, copy2d re-interleave."""
+
+    def __init__(self, be):
+        self.be = be
+
+    def row_block(self, env, lo, hi):
+        W, Db, Dk = env.shape
+        n = hi - lo
+        out = self.be.empty(W, n, Dk)
+        # all W slabs at once: rows [lo, hi) of a (Db x W*Dk) column-major matrix
+        self.be.copy2d(n, W * Dk, env.ptr + 8 * lo, Db, out.ptr, n)
+        return out
+
+    def local_dAC(self, H, GLloc, GR, x):
+        return self.be.dAC(H, GLloc, GR, x)
+
+    def all_gather_rows(self, yloc, group, world):
+        import torch
+        import torch.distributed as dist
+        from .backend import DTensor
+        n, d, Dr = yloc.shape
+        gathered = torch.empty(world * yloc.size, dtype=torch.float64, device=self.be.device)
+        dist.all_gather_into_tensor(gathered, yloc.buf[: yloc.size], group=group)
+        y = self.be.empty(n * world, d, Dr)
+        for p in range(world):   # rank p's block -> rows [p*n, (p+1)*n) of every (s, b) column
+            self.be.copy2d(n, d * Dr, gathered.data_ptr() + 8 * p * yloc.size, n, y.ptr + 8 * p * n, n * world)
+        return y
+
+
+class ShardedMatvec:
+    """Callable y = H_AC x with the bond index sharded over the process group."""
+
+    def __init__(self, plumbing, H, GL, GR, world, rank, group=None):
+        self.pl, self.H, self.GR = plumbing, H, GR
+        self.world, self.rank, self.group = world, rank, group
+        D = GL.shape[1]
+        self.shard = BondShard(D, world, rank)
+        self.GLloc = plumbing.row_block(GL, self.shard.lo, self.shard.hi)
+        self.n_collectives = 0
+
+    def __call__(self, x, out=None):
+        yloc = self.pl.local_dAC(self.H, self.GLloc, self.GR, x)
+        y = self.pl.all_gather_rows(yloc, self.group, self.world)
+        self.n_collectives += 1
+        if out is not None:
+            self.pl.be.axpby(1.0, y, 0.0, out)
+            return out
+        return y
+
+
+def shard_wrapper(be, world, rank, group=None, min_block=64):
+    """Returns wrap(h: MPO_ddAC) -> callable used by dmrg_sweep: sites whose bond dimension is
+    shardable run the sharded matvec, the others (chain edges) run replicated."""
+    pl = DevicePlumbing(be)
+
+    def wrap(h):
+        D = h.leftenv.shape[1]
+        if not BondShard.shardable(D, world, min_block):
+            return h
+        return ShardedMatvec(pl, h.o, h.leftenv, h.rightenv, world, rank, group)
+    return wrap

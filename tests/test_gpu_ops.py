@@ -161,8 +161,28 @@ def test_vectors(be):
 QR_CASES = [(8, 4), (4, 4), (64, 64), (100, 37), (33, 1), (768, 256), (1030, 515), (2048, 1024), (4096, 1024)]
 
 
+@pytest.fixture(params=[0, 1], ids=["qr-auto", "qr-householder"])
+def qr_mode(request, be):
+    """0: shifted CholeskyQR3 with Householder fallback (default); 1: Householder only."""
+    be.set_qr_mode(request.param)
+    yield request.param
+    be.set_qr_mode(0)
+
+
+def test_qrpos_fallback_counts(be):
+    rng = np.random.default_rng(0)
+    s0 = be.qr_stats()
+    be.qrpos(be.upload(rng.random((512, 256))))            # well conditioned -> CholeskyQR3
+    A = rng.random((512, 256))
+    A[:, 7] = 0.0                                            # rank deficient -> Householder fallback
+    be.qrpos(be.upload(A))
+    s1 = be.qr_stats()
+    assert s1["cholqr3"] == s0["cholqr3"] + 1
+    assert s1["fallback"] == s0["fallback"] + 1 and s1["householder"] == s0["householder"] + 1
+
+
 @pytest.mark.parametrize("m,n", QR_CASES)
-def test_qrpos(be, m, n):
+def test_qrpos(be, qr_mode, m, n):
     rng = np.random.default_rng(m * 31 + n)
     A = rng.random((m, n))          # uniform[0,1) like the reference's `rand`
     Q, R = be.qrpos(be.upload(A))
@@ -175,7 +195,7 @@ def test_qrpos(be, m, n):
     assert relerr(R, Rr) < 1e-11 and relerr(Q, Qr) < 1e-10
 
 
-def test_qrpos_illconditioned_and_rank_deficient(be):
+def test_qrpos_illconditioned_and_rank_deficient(be, qr_mode):
     rng = np.random.default_rng(7)
     m, n = 512, 256
     U, _ = np.linalg.qr(rng.standard_normal((m, n)))
