@@ -133,6 +133,7 @@ def main():
     for _ in range(args.warmup):
         alg.dmrg_sweep(psi, H, envs, eig, ws, wrap)
     be.prof_enable(True)
+    qr0 = be.qr_stats()
     barrier()
     t0 = time.perf_counter()
     eps = None
@@ -197,6 +198,7 @@ def main():
             "dAC_tflops": None if dac_tflops is None else round(dac_tflops, 3),
             "dAC_frac_of_fp64_mfma_peak": None if dac_tflops is None else round(dac_tflops / FP64_MFMA_PEAK_TFLOPS, 4),
             "max_galerkin_last_sweep": None if eps is None else float(max(eps)),
+            "qr_calls_timed": {k: be.qr_stats()[k] - qr0[k] for k in qr0},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -49,53 +49,89 @@ __global__ __launch_bounds__(256) void cq_shift_kernel(double* __restrict__ G, i
   for (int i = threadIdx.x; i < n; i += 256) G[i + (int64_t)i * npad] += s;
 }
 
-// In-LDS Cholesky (upper, G_kk = R^T R) and triangular inverse of one 64x64 diagonal block.
+// Cholesky (upper, G_kk = R^T R) and triangular inverse of one 64x64 diagonal block.
+// Thread (i0 = tid >> 6, l = tid & 63) keeps its 16 elements (rows i0 + 4k of column l) in
+// REGISTERS; per elimination step the owners publish the pivot row to a double-buffered LDS row
+// (one barrier per step, 17 independent LDS reads) -- an LDS-resident matrix with read-modify-write
+// per element is latency-bound (~120 us per block, profiles/r01), this form is ~10x faster.
 // Writes R_kk back into G (strict lower part zeroed) and R_kk^{-1} into Rinv's diagonal block.
 __global__ __launch_bounds__(256) void cq_potrf_diag_kernel(double* __restrict__ G, double* __restrict__ Rinv,
                                                             int npad, int k, int* __restrict__ flag) {
-  __shared__ double S[CB][CB + 1];
-  __shared__ double X[CB][CB + 1];
+  __shared__ double S[CB][CB + 1];       // R (written once after the factorisation)
+  __shared__ double rowbuf[2][CB];
+  __shared__ double dsq[CB];
+  __shared__ double dinvd[CB];           // 1 / R[i][i]
   __shared__ int bad;
   const int tid = threadIdx.x;
+  const int l = tid & 63, i0 = tid >> 6;
   double* Gk = G + (int64_t)k * CB * (npad + 1);
   double* Rk = Rinv + (int64_t)k * CB * (npad + 1);
   if (tid == 0) bad = 0;
-  for (int e = tid; e < CB * CB; e += 256) S[e % CB][e / CB] = Gk[(e % CB) + (int64_t)(e / CB) * npad];
-  __syncthreads();
+  double a[CB / 4];
+#pragma unroll
+  for (int kk = 0; kk < CB / 4; ++kk) a[kk] = Gk[(i0 + 4 * kk) + (int64_t)l * npad];
   for (int j = 0; j < CB; ++j) {
-    const double piv = S[j][j];
-    if (!(piv > 0.0) || !isfinite(piv)) { if (tid == 0) bad = 1; }
-    const double dinv = (piv > 0.0) ? 1.0 / sqrt(piv) : 0.0;
-    __syncthreads();
-    // row j of R
-    if (tid < CB) {
-      if (tid > j) S[j][tid] *= dinv;
-      else if (tid == j) S[j][j] = (piv > 0.0) ? sqrt(piv) : 1.0;
+    if (i0 == (j & 3)) {                 // owners of row j publish it (unscaled)
+      double v = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < CB / 4; ++kk) if (kk == (j >> 2)) v = a[kk];
+      rowbuf[j & 1][l] = v;
     }
     __syncthreads();
-    // trailing update of the upper triangle: S[i][l] -= R[j][i] R[j][l], j < i <= l
-    const int rem = CB - 1 - j;
-    for (int e = tid; e < rem * rem; e += 256) {
-      const int i = j + 1 + e % rem, l = j + 1 + e / rem;
-      if (i <= l) S[i][l] -= S[j][i] * S[j][l];
-    }
-    __syncthreads();
-  }
-  // inverse of the upper-triangular R: column c by back substitution (one thread per column)
-  if (tid < CB) {
-    const int c = tid;
-    for (int i = CB - 1; i > c; --i) X[i][c] = 0.0;
-    for (int i = c; i >= 0; --i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int l = i + 1; l <= c; ++l) s -= S[i][l] * X[l][c];
-      X[i][c] = s / S[i][i];
+    const double* rb = rowbuf[j & 1];
+    const double piv = rb[j];
+    const bool ok = (piv > 0.0) && isfinite(piv);
+    const double dinv2 = ok ? 1.0 / piv : 0.0;
+    if (tid == 0) { const double sq = ok ? sqrt(piv) : 1.0; dsq[j] = sq; dinvd[j] = 1.0 / sq; if (!ok) bad = 1; }
+    const double sjl = rb[l] * dinv2;
+    double rv[CB / 4];                   // issue all LDS reads back-to-back (one wait), then branch-free math
+#pragma unroll
+    for (int kk = 0; kk < CB / 4; ++kk) rv[kk] = rb[i0 + 4 * kk];
+#pragma unroll
+    for (int kk = 0; kk < CB / 4; ++kk) {
+      const int i = i0 + 4 * kk;
+      const double upd = rv[kk] * sjl;
+      a[kk] -= (i > j && i <= l) ? upd : 0.0;
     }
   }
   __syncthreads();
-  for (int e = tid; e < CB * CB; e += 256) {
-    const int r = e % CB, c = e / CB;
-    Gk[r + (int64_t)c * npad] = (r <= c) ? S[r][c] : 0.0;
-    Rk[r + (int64_t)c * npad] = X[r][c];
+  // R[i][l] = a / dsq[i] (i < l), dsq[i] on the diagonal, 0 below
+#pragma unroll
+  for (int kk = 0; kk < CB / 4; ++kk) {
+    const int i = i0 + 4 * kk;
+    const double r = (i < l) ? a[kk] * dinvd[i] : (i == l ? dsq[i] : 0.0);
+    S[i][l] = r;
+    Gk[i + (int64_t)l * npad] = r;
+  }
+  __syncthreads();
+  // inverse: x[kk] = Y[i0 + 4kk][c] (unscaled rows), step i: xi = Y[i][c] / R[i][i], rows above -= R[r][i] xi
+  const int c = l;
+  double x[CB / 4];
+#pragma unroll
+  for (int kk = 0; kk < CB / 4; ++kk) x[kk] = ((i0 + 4 * kk) == c) ? 1.0 : 0.0;
+  for (int i = CB - 1; i >= 0; --i) {
+    if (i0 == (i & 3)) {
+      double v = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < CB / 4; ++kk) if (kk == (i >> 2)) v = x[kk];
+      rowbuf[i & 1][c] = v;
+    }
+    __syncthreads();
+    const double xi = rowbuf[i & 1][c] * dinvd[i];
+    double sv[CB / 4];
+#pragma unroll
+    for (int kk = 0; kk < CB / 4; ++kk) sv[kk] = S[i0 + 4 * kk][i];
+#pragma unroll
+    for (int kk = 0; kk < CB / 4; ++kk) {
+      const int r = i0 + 4 * kk;
+      const double upd = sv[kk] * xi;
+      x[kk] -= (r < i && c >= i) ? upd : 0.0;
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < CB / 4; ++kk) {
+    const int r = i0 + 4 * kk;
+    Rk[r + (int64_t)c * npad] = (r <= c) ? x[kk] * dinvd[r] : 0.0;
   }
   if (tid == 0 && bad) atomicOr(flag, 1);
 }
@@ -198,6 +234,39 @@ __global__ __launch_bounds__(256) void cq_copy_upper_kernel(const double* __rest
   }
 }
 
+// Third pass when Q2 is already orthogonal to ~1e-7: chol(I + E) = I + U + O(E^2) with
+// U = striu(E) + diag(E)/2, so  R3 = I + U,  R3^{-1} = I - U  and  Q3 = Q2 (I - U) is orthogonal
+// to O(|E|^2) <= 1e-14 -- no Cholesky, no inverse.  Sets flag bit 4 when max|E| > 1e-7 (the
+// caller then repeats the pass with the full Cholesky).
+__global__ __launch_bounds__(256) void cq_firstorder_kernel(const double* __restrict__ G, int npad, int n,
+                                                            double* __restrict__ R3, double* __restrict__ Minv,
+                                                            int* __restrict__ flag) {
+  const int64_t total = (int64_t)npad * npad;
+  int big = 0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e % npad), c = (int)(e / npad);
+    double u = 0.0, id = (r == c) ? 1.0 : 0.0;
+    if (r < n && c < n) {
+      const double ev = G[e] - id;
+      if (!(fabs(ev) <= 1.0e-7)) big = 1;
+      u = (r < c) ? ev : (r == c ? 0.5 * ev : 0.0);
+    }
+    R3[e] = id + u;
+    Minv[e] = id - u;
+  }
+  if (big) atomicOr(flag, 4);
+}
+
+static hipError_t cq_pass_firstorder(int m, int n, int npad, const double* X, int ldx, double* Q, int ldq, double* Rp,
+                                     double* Rinv, double* T, int* flag, hipStream_t s) {
+  hipError_t e;
+  GemmArgs g = cq_mk(X, X, T, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X  (into T)
+  if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(cq_firstorder_kernel, dim3(1024), dim3(256), 0, s, T, npad, n, Rp, Rinv, flag);
+  g = cq_mk(X, Rinv, Q, m, n, n, ldx, npad, ldq, 0, 1.0, 0.0);
+  return gemm_f64(g, s);
+}
+
 // Shifted CholeskyQR3.  *flag_out != 0 (host, after a stream sync) means "not trustworthy, fall back".
 hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                    int* d_flag, int* flag_out, hipStream_t s) {
@@ -209,18 +278,25 @@ hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, d
   double* Rinv = R3 + np2; double* T = Rinv + np2;
   double* Qa = T + np2; double* Qb = Qa + (size_t)m * n;
   hipError_t e;
+  auto finish = [&]() -> hipError_t {   // R = R3 R2 R1 ; flag to host
+    GemmArgs g = cq_mk(R2, R1, T, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
+    if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+    g = cq_mk(R3, T, Rinv, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
+    if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(cq_copy_upper_kernel, dim3(1024), dim3(256), 0, s, Rinv, npad, n, R, ldr);
+    if ((e = hipMemcpyAsync(flag_out, d_flag, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+  };
   if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
   if ((e = cq_pass(m, n, npad, A, lda, Qa, m, R1, Rinv, T, true, false, d_flag, s)) != hipSuccess) return e;
   if ((e = cq_pass(m, n, npad, Qa, m, Qb, m, R2, Rinv, T, false, false, d_flag, s)) != hipSuccess) return e;
-  if ((e = cq_pass(m, n, npad, Qb, m, Q, ldq, R3, Rinv, T, false, true, d_flag, s)) != hipSuccess) return e;
-  // R = R3 R2 R1
-  GemmArgs g = cq_mk(R2, R1, T, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
-  if ((e = gemm_f64(g, s)) != hipSuccess) return e;
-  g = cq_mk(R3, T, Rinv, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
-  if ((e = gemm_f64(g, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(cq_copy_upper_kernel, dim3(1024), dim3(256), 0, s, Rinv, npad, n, R, ldr);
-  if ((e = hipMemcpyAsync(flag_out, d_flag, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+  if ((e = cq_pass_firstorder(m, n, npad, Qb, m, Q, ldq, R3, Rinv, T, d_flag, s)) != hipSuccess) return e;
+  if ((e = finish()) != hipSuccess) return e;
+  if (*flag_out == 4) {                 // Q2 not yet orthogonal to 1e-7: full third pass
+    if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
+    if ((e = cq_pass(m, n, npad, Qb, m, Q, ldq, R3, Rinv, T, false, true, d_flag, s)) != hipSuccess) return e;
+    if ((e = finish()) != hipSuccess) return e;
+  }
   return hipGetLastError();
 }
 

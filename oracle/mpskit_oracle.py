@@ -255,10 +255,13 @@ def dense_hamiltonian(H: MPOHamiltonian, L):
 # --------------------------------------------------------------------------------------
 
 def dAC_block(x, O, GLi, GRj):
-    """derivatives.jl:95-104.  O dense [chi,d,d,chi] or scalar."""
-    if np.isscalar(O):
-        return O * np.einsum("pwa,asb,bwq->psq", GLi, x, GRj, optimize=True)
-    return np.einsum("pwa,asb,wtsv,bvq->ptq", GLi, x, O, GRj, optimize=True)
+    """derivatives.jl:95-104.  O dense [chi,d,d,chi] or scalar.  Evaluated pairwise through BLAS
+    GEMMs (np.tensordot), the way TensorOperations executes the reference's @plansor."""
+    t1 = np.tensordot(GLi, x, axes=([2], [0]))                    # [p, w, s, b]
+    if np.isscalar(O):                                            # tau braiding: t = s, v = w
+        return O * np.tensordot(t1, GRj, axes=([3, 1], [0, 1]))   # [p, s, q]
+    t2 = np.tensordot(t1, O, axes=([1, 2], [0, 2]))               # [p, b, t, v]
+    return np.tensordot(t2, GRj, axes=([1, 3], [0, 1]))           # [p, t, q]
 
 
 def dAC(x, H: SparseMPOSlice, GL, GR):
@@ -274,7 +277,7 @@ def dC(x, GL, GR):
     """derivatives.jl:171-189."""
     y = None
     for le, re in zip(GL, GR):
-        t = np.einsum("pwa,ab,bwq->pq", le, x, re, optimize=True)
+        t = np.tensordot(np.tensordot(le, x, axes=([2], [0])), re, axes=([2, 1], [0, 1]))   # [p, q]
         y = t if y is None else y + t
     return y
 
@@ -298,17 +301,23 @@ def dAC2(x, h1: SparseMPOSlice, h2: SparseMPOSlice, GL, GR):
 
 
 def transfer_left_block(v, O, A, Ab):
-    """transfer.jl:105-107 (dense) / :66-70 (pass-through leg)."""
+    """transfer.jl:105-107 (dense) / :66-70 (pass-through leg); pairwise BLAS contractions."""
+    t1 = np.tensordot(v, A, axes=([2], [0]))                          # [p, w, s, b]
     if O is None:
-        return np.einsum("pwa,asb,psq->qwb", v, A, np.conj(Ab), optimize=True)
-    return np.einsum("pwa,asb,wtsv,ptq->qvb", v, A, O, np.conj(Ab), optimize=True)
+        return np.tensordot(np.conj(Ab), t1, axes=([0, 1], [0, 2]))   # [q, w, b]
+    t2 = np.tensordot(t1, O, axes=([1, 2], [0, 2]))                   # [p, b, t, v]
+    out = np.tensordot(np.conj(Ab), t2, axes=([0, 1], [0, 2]))        # [q, b, v]
+    return np.transpose(out, (0, 2, 1))                               # [q, v, b]
 
 
 def transfer_right_block(v, O, A, Ab):
     """transfer.jl:108-110 / :71-75."""
+    t1 = np.tensordot(v, np.conj(Ab), axes=([2], [2]))                # [b, v, p, t]
     if O is None:
-        return np.einsum("asb,psq,bwq->awp", A, np.conj(Ab), v, optimize=True)
-    return np.einsum("asb,wtsv,ptq,bvq->awp", A, O, np.conj(Ab), v, optimize=True)
+        out = np.tensordot(A, t1, axes=([1, 2], [3, 0]))              # [a, w, p]   (s = t, w = v)
+        return out
+    t2 = np.tensordot(O, t1, axes=([1, 3], [3, 1]))                   # [w, s, b, p]
+    return np.tensordot(A, t2, axes=([1, 2], [1, 2]))                 # [a, w, p]
 
 
 def transfer_left(vec, ham: SparseMPOSlice, A, Ab):
