@@ -67,7 +67,7 @@ class MPOHamiltonian:
                         blocks[(i, j)] = 1.0 if abs(c - 1) < 1e-14 else c
                         continue
                 blocks[(i, j)] = a
-            self.slices.append(DeviceMPOSlice(self.be, odim, self.d, chis[s], chis[s + 1], blocks))
+            self.slices.append(self.be.mposlice(odim, self.d, chis[s], chis[s + 1], blocks))
         self._energy_slices = {}
 
     def __getitem__(self, i):
@@ -93,7 +93,7 @@ class MPOHamiltonian:
                     continue
                 f = 1.0 if (j == 0 and k == odim - 1) else 0.5
                 blocks[(j, k)] = f * v if np.isscalar(v) else f * np.asarray(v)
-            self._energy_slices[key] = DeviceMPOSlice(self.be, odim, self.d, s.chil, s.chir, blocks)
+            self._energy_slices[key] = self.be.mposlice(odim, self.d, s.chil, s.chir, blocks)
         return self._energy_slices[key]
 
 

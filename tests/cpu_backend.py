@@ -1,0 +1,224 @@
+"""TEST INFRASTRUCTURE: a host stand-in for `mpskit_jl_amd.backend.Backend`.
+
+It lets the `-m "not gpu"` suite exercise the PRODUCT's host logic (lazy-gauge FiniteMPS, FinEnv
+invalidation, Krylov loops, DMRG driver, bond-sharding plumbing) without a GPU: same method
+names / argument conventions as Backend, DTensor buffers are CPU torch tensors holding the same
+column-major data, arithmetic is done by NumPy / the oracle.  It is never imported by the
+product package (which has no CPU fallback)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import mpskit_oracle as mo
+from mpskit_jl_amd.backend import DTensor
+
+
+def _view(ptr, n):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,))
+
+
+class HostSlice:
+    def __init__(self, odim, d, chil, chir, blocks):
+        self.odim, self.d = odim, d
+        self.chil, self.chir = list(chil), list(chir)
+        self.Wl, self.Wr = sum(chil), sum(chir)
+        self.blocks = dict(blocks)
+        self.oracle = mo.SparseMPOSlice(odim, d, chil, chir, {k: v for k, v in blocks.items()})
+        self.handle = None
+
+    def keys(self):
+        return self.oracle.keys()
+
+    def contains(self, i, j):
+        return self.oracle.contains(i, j)
+
+    def isscal(self, i, j):
+        return self.oracle.isscal(i, j)
+
+
+class CpuBackend:
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.calls = {}
+        self._qr = {"cholqr3": 0, "householder": 0, "fallback": 0}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    # ---- memory ----
+    def empty(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        n = int(np.prod(shape)) if len(shape) else 1
+        return DTensor(torch.zeros(max(n, 1), dtype=torch.float64), shape)
+
+    zeros = empty
+
+    def upload(self, a, shape=None):
+        a = np.asarray(a, dtype=np.float64)
+        flat = np.ravel(a, order="F").copy()
+        if flat.size == 0:
+            flat = np.zeros(1)
+        return DTensor(torch.from_numpy(flat), a.shape if shape is None else shape)
+
+    def download(self, t):
+        return t.buf[: t.size].numpy().reshape(t.shape, order="F").copy()
+
+    def _set(self, t, arr):
+        t.buf[: t.size] = torch.from_numpy(np.ravel(np.asarray(arr, dtype=np.float64), order="F").copy())
+        return t
+
+    def upload_env(self, blocks):
+        slabs = [np.asarray(b)[:, k, :] for b in blocks for k in range(np.asarray(b).shape[1])]
+        flat = np.concatenate([np.ravel(s, order="F") for s in slabs])
+        return DTensor(torch.from_numpy(flat.copy()), (len(slabs),) + slabs[0].shape)
+
+    def _env(self, t, chis):
+        W, Db, Dk = t.shape
+        flat = t.buf[: t.size].numpy()
+        slabs = [flat[w * Db * Dk:(w + 1) * Db * Dk].reshape((Db, Dk), order="F") for w in range(W)]
+        out, o = [], 0
+        for chi in chis:
+            out.append(np.stack(slabs[o:o + chi], axis=1))
+            o += chi
+        return out
+
+    download_env = _env
+
+    def _put_env(self, blocks, out=None):
+        t = self.upload_env(blocks)
+        if out is not None:
+            out.buf[: t.size] = t.buf[: t.size]
+            return out
+        return t
+
+    def copy(self, t):
+        return DTensor(t.buf.clone(), t.shape)
+
+    def synchronize(self):
+        pass
+
+    def mposlice(self, odim, d, chil, chir, blocks):
+        return HostSlice(odim, d, chil, chir, blocks)
+
+    # ---- operators (oracle arithmetic) ----
+    def dAC(self, H, GL, GR, x, out=None):
+        self._count("dAC")
+        gl = self._env(GL, H.chil)
+        y = mo.dAC(self.download(x), H.oracle, gl, self._env(GR, H.chir))
+        if y is None:
+            y = np.zeros((GL.shape[1],) + x.shape[1:])
+        o = self.empty(GL.shape[1], x.shape[1], x.shape[2]) if out is None else out
+        return self._set(o, y)
+
+    def dC(self, GL, GR, c, out=None):
+        self._count("dC")
+        W = GL.shape[0]
+        y = mo.dC(self.download(c), self._env(GL, [1] * W), self._env(GR, [1] * W))
+        o = self.empty(GL.shape[1], c.shape[1]) if out is None else out
+        return self._set(o, y)
+
+    def transfer_left(self, H, GLin, A, Ab, out=None):
+        self._count("transfer_left")
+        a, ab = self.download(A), self.download(Ab)
+        if H is None:
+            W = GLin.shape[0]
+            res = [mo.transfer_left_block(v, None, a, ab) for v in self._env(GLin, [1] * W)]
+        else:
+            res = mo.transfer_left(self._env(GLin, H.chil), H.oracle, a, ab)
+        return self._put_env(res, out)
+
+    def transfer_right(self, H, GRin, A, Ab, out=None):
+        self._count("transfer_right")
+        a, ab = self.download(A), self.download(Ab)
+        if H is None:
+            W = GRin.shape[0]
+            res = [mo.transfer_right_block(v, None, a, ab) for v in self._env(GRin, [1] * W)]
+        else:
+            res = mo.transfer_right(self._env(GRin, H.chir), H.oracle, a, ab)
+        return self._put_env(res, out)
+
+    def regularize(self, v, lvec, rvec):
+        W = v.shape[0]
+        l, r = self.download(lvec), self.download(rvec)
+        res = [mo.regularize_env(e, l, r) for e in self._env(v, [1] * W)]
+        self._put_env(res, v)
+        return v
+
+    def gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, **kw):
+        a, b = self.download(A), self.download(B)
+        r = alpha * (a.T if transA else a) @ (b.T if transB else b)
+        if out is None:
+            return self.upload(r)
+        if beta != 0.0:
+            r = r + beta * self.download(out.reshape(r.shape))
+        return self._set(out, r)
+
+    def gemm_raw(self, tA, tB, M, N, K, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc):
+        ar, ac = (K, M) if tA else (M, K)
+        br, bc = (N, K) if tB else (K, N)
+        a = _view(a_ptr, lda * ac).reshape((lda, ac), order="F")[:ar]
+        b = _view(b_ptr, ldb * bc).reshape((ldb, bc), order="F")[:br]
+        c = _view(c_ptr, ldc * N).reshape((ldc, N), order="F")
+        r = alpha * (a.T if tA else a) @ (b.T if tB else b)
+        c[:M] = r + (beta * c[:M] if beta != 0.0 else 0.0)
+
+    def copy2d(self, rows, cols, src_ptr, lds, dst_ptr, ldd):
+        s = _view(src_ptr, lds * cols).reshape((lds, cols), order="F")
+        d = _view(dst_ptr, ldd * cols).reshape((ldd, cols), order="F")
+        d[:rows] = s[:rows]
+
+    def qrpos(self, A):
+        self._count("qrpos")
+        q, r = mo.qrpos(self.download(A))
+        return self.upload(q), self.upload(r)
+
+    def lqpos(self, A):
+        self._count("lqpos")
+        l, q = mo.lqpos(self.download(A))
+        return self.upload(l), self.upload(q)
+
+    def qr_stats(self):
+        return dict(self._qr)
+
+    # ---- vectors ----
+    def _v(self, x):
+        return x.buf[: x.size].numpy()
+
+    def dot(self, x, y):
+        return float(self._v(x) @ self._v(y))
+
+    def norm(self, x):
+        return float(np.linalg.norm(self._v(x)))
+
+    def axpby(self, alpha, x, beta, y):
+        v = alpha * self._v(x) + (beta * self._v(y) if beta != 0.0 else 0.0)
+        y.buf[: y.size] = torch.from_numpy(np.ascontiguousarray(v))
+        return y
+
+    def scal(self, alpha, x):
+        x.buf[: x.size] *= alpha
+        return x
+
+    def multidot(self, xs, y):
+        return np.array([self.dot(x, y) for x in xs])
+
+    def gs_step(self, xs, y):
+        h = self.multidot(xs, y)
+        v = self._v(y) - sum(c * self._v(x) for c, x in zip(h, xs))
+        y.buf[: y.size] = torch.from_numpy(np.ascontiguousarray(v))
+        return h
+
+    def lincomb(self, xs, coefs, out=None):
+        y = self.empty(xs[0].shape) if out is None else out
+        v = sum(float(c) * self._v(x) for c, x in zip(coefs, xs))
+        y.buf[: y.size] = torch.from_numpy(np.ascontiguousarray(v))
+        return y
+
+    def prof_enable(self, on=True):
+        pass
+
+    def prof_summary(self):
+        return []

@@ -1,0 +1,92 @@
+"""HIP path vs the committed golden fixtures (tests/golden/hotpath_vectors.npz) and size-independent
+properties at the benchmark's full size (D = 1024): linearity, Hermiticity of the effective
+Hamiltonian on symmetric environments, QR / transfer identities."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_golden_case_A(be):
+    import mpskit_jl_amd as mk
+    g = np.load(os.path.join(GOLD, "hotpath_vectors.npz"))
+    H = mk.heisenberg_XXX(0.5, be=be)[0]
+    GL = be.upload_env([a[:, None, :] for a in g["A_GL"][:, :, 0, :]])
+    GR = be.upload_env([a[:, None, :] for a in g["A_GR"][:, :, 0, :]])
+    assert relerr(be.download(be.dAC(H, GL, GR, be.upload(g["A_x"]))), g["A_dAC"]) < 1e-13
+    assert relerr(be.download(be.dC(GL, GR, be.upload(g["A_c"]))), g["A_dC"]) < 1e-13
+    assert relerr(be.download(be.dAC2(H, H, GL, GR, be.upload(g["A_x2"]))), g["A_dAC2"]) < 1e-13
+    tl = be.download_env(be.transfer_left(H, GL, be.upload(g["A_A"]), be.upload(g["A_Ab"])), [1] * 5)
+    tr = be.download_env(be.transfer_right(H, GR, be.upload(g["A_A"]), be.upload(g["A_Ab"])), [1] * 5)
+    assert relerr(np.stack(tl), g["A_tl"]) < 1e-13 and relerr(np.stack(tr), g["A_tr"]) < 1e-13
+    q, r = be.qrpos(be.upload(g["G_M"]))
+    assert relerr(be.download(q), g["G_Q"]) < 1e-12 and relerr(be.download(r), g["G_R"]) < 1e-12
+    l, qq = be.lqpos(be.upload(g["G_M"].T.copy()))
+    assert relerr(be.download(l), g["G_L"]) < 1e-12 and relerr(be.download(qq), g["G_LQ"]) < 1e-12
+    th = g["G_theta"]
+    U, S, Vh, kept, disc = be.tsvd(be.upload(th).reshape(12, 14), max_keep=5)
+    # oracle tsvd orders the columns (s2, b); singular values and discarded weight are order independent
+    assert kept == 5 and relerr(be.download(S)[:5], g["G_S"]) < 1e-13 and abs(disc - float(g["G_err"])) < 1e-13
+
+
+def test_golden_case_B_chi_gt_1(be):
+    g = np.load(os.path.join(GOLD, "hotpath_vectors.npz"))
+    chis = [int(c) for c in g["B_chis"]]
+    blocks = {}
+    for k in g.files:
+        if k.startswith("B_O_"):
+            _, _, i, j = k.split("_")
+            blocks[(int(i), int(j))] = g[k]
+    s = be.mposlice(len(chis), 2, chis, chis, blocks)
+    GL = be.upload_env([g[f"B_GL{i}"] for i in range(len(chis))])
+    GR = be.upload_env([g[f"B_GR{i}"] for i in range(len(chis))])
+    assert relerr(be.download(be.dAC(s, GL, GR, be.upload(g["B_x"]))), g["B_dAC"]) < 1e-13
+
+
+def test_full_size_properties(be):
+    """D = 1024, d = 2, W = 5 (BASELINE north-star point): no oracle run, only identities."""
+    import torch
+    import mpskit_jl_amd as mk
+    D, d, W = 1024, 2, 5
+    H = mk.heisenberg_XXX(0.5, be=be)[0]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: be.upload(torch.rand(*s, generator=g, dtype=torch.float64).numpy() - 0.5)
+    # symmetric environments -> the effective Hamiltonian is symmetric: <u, H v> = <H u, v>
+    gl = torch.rand(W, D, D, generator=g, dtype=torch.float64).numpy() - 0.5
+    gl = gl + np.transpose(gl, (0, 2, 1))
+    GL = be.upload_env([m[:, None, :] for m in gl])
+    GR = be.upload_env([m[:, None, :] for m in gl[::-1]])
+    u, v = rnd(D, d, D), rnd(D, d, D)
+    Hu, Hv = be.dAC(H, GL, GR, u), be.dAC(H, GL, GR, v)
+    a, b = be.dot(u, Hv), be.dot(Hu, v)
+    assert abs(a - b) < 1e-10 * max(abs(a), abs(b), 1.0) * D
+    # linearity: H(2u - 3v) = 2 Hu - 3 Hv
+    w = be.copy(u)
+    be.axpby(-3.0, v, 2.0, w)
+    Hw = be.dAC(H, GL, GR, w)
+    be.axpby(-2.0, Hu, 1.0, Hw)
+    be.axpby(3.0, Hv, 1.0, Hw)
+    assert be.norm(Hw) < 1e-11 * be.norm(Hu)
+    # QRpos identities at the sweep's size: Q^T Q = I, Q R = A (checked through traces / norms on device)
+    A = rnd(2 * D, D)
+    Q, R = be.qrpos(A)
+    QtQ = be.gemm(Q, Q, transA=True)
+    eye = be.upload(np.eye(D))
+    be.axpby(-1.0, eye, 1.0, QtQ)
+    assert be.norm(QtQ) < 1e-11
+    QR = be.gemm(Q, R)
+    be.axpby(-1.0, A, 1.0, QR)
+    assert be.norm(QR) < 1e-11 * be.norm(A)
+    # transfer of the identity through an isometry is the identity (test/states.jl:62-70)
+    AL = mk.DTensor(Q.buf, (D, d, D))
+    one = be.upload(np.eye(D)[None]).reshape(1, D, D)
+    out = be.transfer_left(None, one, AL, AL)
+    be.axpby(-1.0, eye, 1.0, mk.DTensor(out.buf, (D, D)))
+    assert be.norm(mk.DTensor(out.buf, (D, D))) < 1e-11

@@ -1,0 +1,155 @@
+"""Pins the oracle (CPU restatement of the reference) WITHOUT the reference being runnable here:
+ (1) ED identity of src/algorithms/ED.jl:4-53, (2) exact diagonalisation / free fermions,
+ (3) energies recorded in the reference's docs (tests/golden/reference_recorded.json),
+ (4) the reference's own property tests (test/states.jl:25-28,62-70; test/operators.jl:59-74,207-225),
+ (5) the committed golden vectors (regression)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import mpskit_oracle as mo
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REC = json.load(open(os.path.join(GOLD, "reference_recorded.json")))
+
+
+def _embed_matrix(psi, pos):
+    """isometry P with |psi(AC)> = P vec(AC): left part from AL, right part from AR."""
+    L = len(psi)
+    left = np.ones((1, 1))
+    for i in range(pos):
+        al = psi.AL(i)
+        left = np.einsum("xa,asb->xsb", left, al).reshape(-1, al.shape[2])
+    right = np.ones((1, 1))
+    for i in range(L - 1, pos, -1):
+        ar = psi.AR(i)
+        right = np.einsum("asb,by->asy", ar, right).reshape(ar.shape[0], -1)
+    return left, right
+
+
+@pytest.mark.parametrize("model", ["heis", "tfi2", "hub"])
+def test_dAC_is_projected_dense_hamiltonian(model):
+    """ED.jl:4-53 : dAC == P^dag H_dense P on every site of a random MPS."""
+    rng = np.random.default_rng(3)
+    H, d, L, D = {"heis": (mo.heisenberg_mpo(0.5), 2, 6, 5), "tfi2": (mo.tfi_twosite_mpo(0.8), 2, 6, 4),
+                  "hub": (mo.hubbard_mpo(1.0, 3.0), 4, 4, 6)}[model]
+    psi = mo.FiniteMPS.random(L, d, D, rng)
+    envs = mo.FinEnv(psi, H)
+    Hd = mo.dense_hamiltonian(H, L)
+    for pos in (0, L // 2, L - 1):
+        ac = psi.AC(pos)
+        left, right = _embed_matrix(psi, pos)
+        GL, GR = envs.leftenv(pos, psi), envs.rightenv(pos, psi)
+        x = rng.standard_normal(ac.shape)
+        y = mo.dAC(x, envs.opp[pos], GL, GR)
+        full = np.einsum("xa,asb,by->xsy", left, x, right).reshape(-1)
+        yfull = (Hd @ full).reshape(left.shape[0], d, right.shape[1])
+        yproj = np.einsum("xa,xsy,by->asb", left, yfull, right)
+        assert np.abs(y - yproj).max() < 1e-12 * max(1.0, np.abs(yproj).max())
+
+
+@pytest.mark.parametrize("model", ["heis", "tfi", "hub", "tfi2", "heis1"])
+def test_dmrg_equals_exact_diagonalisation(model):
+    """test/algorithms.jl:512-540 style: DMRG energy == ED energy (here to 1e-10, untruncated D)."""
+    rng = np.random.default_rng(1)
+    H, d, L = {"heis": (mo.heisenberg_mpo(0.5), 2, 8), "tfi": (mo.tfi_mpo(1.0, 0.5), 2, 8),
+               "hub": (mo.hubbard_mpo(), 4, 5), "tfi2": (mo.tfi_twosite_mpo(1.0), 2, 8),
+               "heis1": (mo.heisenberg_mpo(1.0), 3, 5)}[model]
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(H, L))[0]
+    psi = mo.FiniteMPS.random(L, d, 64, rng)
+    _, _, eps, log = mo.dmrg(psi, H, maxiter=10, tol=1e-10)
+    assert abs(log[-1][1] - e0) < 1e-10 * abs(e0)
+
+
+def test_hubbard_free_fermion_limit():
+    """U = 0 Hubbard chain = two copies of free fermions: E0 = 2 * sum of negative -2t cos(k pi/(L+1))."""
+    L = 6
+    H = mo.hubbard_mpo(1.0, 0.0)
+    eps_k = -2.0 * np.cos(np.arange(1, L + 1) * np.pi / (L + 1))
+    e_exact = 2.0 * eps_k[eps_k < 0].sum()
+    psi = mo.FiniteMPS.random(L, 4, 64, np.random.default_rng(2))
+    _, _, _, log = mo.dmrg(psi, H, maxiter=12, tol=1e-9)
+    assert abs(log[-1][1] - e_exact) < 1e-8
+
+
+def test_reference_recorded_dmrg_energy():
+    r = REC["dmrg_tfi_obc_L20_D10"]
+    psi = mo.FiniteMPS.random(20, 2, 10, np.random.default_rng(1))
+    _, _, _, log = mo.dmrg(psi, mo.tfi_mpo(1.0, 0.5), maxiter=10, tol=1e-9)
+    assert abs(log[-1][1] - r["value"]) < 1e-10
+
+
+def test_reference_recorded_vumps_energy():
+    r = REC["vumps_tfi_inf_D10"]
+    psi = mo.InfiniteMPS.random(2, 10, np.random.default_rng(1))
+    _, _, eps, log = mo.vumps(psi, mo.tfi_mpo(1.0, 0.5), maxiter=40, tol=1e-10)
+    assert eps < 1e-9
+    assert abs(log[-1][1] - r["value"]) < 2e-12
+
+
+def test_gauge_identities():
+    """test/states.jl:25-28."""
+    psi = mo.FiniteMPS.random(7, 3, 9, np.random.default_rng(4))
+    for i in range(7):
+        ac = psi.AC(i)
+        assert np.abs(np.einsum("asb,bk->ask", psi.AL(i), psi.CR(i)) - ac).max() < 1e-13
+        assert np.abs(np.einsum("ka,asb->ksb", psi.CR(i - 1), psi.AR(i)) - ac).max() < 1e-13
+    assert abs(psi.norm() - 1) < 1e-13
+
+
+def test_uniform_gauge_fixed_points():
+    """test/states.jl:57-70 : AL*CR = CR*AR and l_LL*T = l_LL, T*r_RR = r_RR for an InfiniteMPS."""
+    psi = mo.InfiniteMPS.random(2, 7, np.random.default_rng(5), n=2)
+    for i in range(2):
+        lhs = np.einsum("asb,bk->ask", psi.AL[i], psi.CR[i])
+        rhs = np.einsum("ka,asb->ksb", psi.CR[i - 1], psi.AR[i])
+        assert np.abs(lhs - rhs).max() < 1e-11
+        eye = np.eye(7)
+        assert np.abs(mo.transfer_left_bond(eye, psi.AL[i], psi.AL[i]) - eye).max() < 1e-12
+        assert np.abs(mo.transfer_right_bond(eye, psi.AR[i], psi.AR[i]) - eye).max() < 1e-12
+
+
+def test_derivative_and_expval_linearity():
+    """test/operators.jl:59-74,207-225 : expectation values / derivatives are linear in H."""
+    rng = np.random.default_rng(6)
+    L, d = 6, 2
+    psi = mo.FiniteMPS.random(L, d, 8, rng)
+    H1, H2 = mo.tfi_mpo(1.0, 0.3), mo.tfi_mpo(0.0, 0.9)
+    Hs = mo.tfi_mpo(1.0, 1.2)          # H1 + H2
+    e = [np.sum(mo.expectation_value(psi, H, mo.FinEnv(psi, H))) for H in (H1, H2, Hs)]
+    assert abs(e[0] + e[1] - e[2]) < 1e-10
+    D = 6
+    GL = [rng.standard_normal((D, 1, D)) for _ in range(3)]
+    GR = [rng.standard_normal((D, 1, D)) for _ in range(3)]
+    x = rng.standard_normal((D, d, D))
+    b1 = {(0, 1): rng.standard_normal((d, d)), (1, 2): rng.standard_normal((d, d))}
+    b2 = {(0, 2): rng.standard_normal((d, d))}
+    s1, s2 = mo.mpoham_from_chain(b1, d), mo.mpoham_from_chain({**b2, (1, 1): 0.0}, d)
+    ss = mo.mpoham_from_chain({**b1, **b2}, d)
+    assert np.abs(mo.dAC(x, s1, GL, GR) + mo.dAC(x, s2, GL, GR) - mo.dAC(x, ss, GL, GR)).max() < 1e-12
+
+
+def test_tsvd_truncation_semantics():
+    rng = np.random.default_rng(7)
+    th = rng.random((6, 2, 7, 2))
+    U, S, Vh, err = mo.tsvd(th, truncdim=5)
+    assert len(S) == 5
+    full = np.linalg.svd(np.transpose(th, (0, 1, 3, 2)).reshape(12, 14), compute_uv=False)
+    assert np.allclose(S, full[:5]) and abs(err - np.linalg.norm(full[5:])) < 1e-13
+    U, S, Vh, err = mo.tsvd(th, truncerr=0.2)
+    assert np.linalg.norm(full[len(S):]) <= 0.2 * np.linalg.norm(full) < np.linalg.norm(full[len(S) - 1:]) + 1e-15
+
+
+def test_golden_vectors_regression():
+    g = np.load(os.path.join(GOLD, "hotpath_vectors.npz"))
+    H = mo.heisenberg_mpo(0.5)[0]
+    GL, GR = list(g["A_GL"]), list(g["A_GR"])
+    assert np.abs(mo.dAC(g["A_x"], H, GL, GR) - g["A_dAC"]).max() < 1e-12
+    assert np.abs(mo.dC(g["A_c"], GL, GR) - g["A_dC"]).max() < 1e-12
+    assert np.abs(mo.dAC2(g["A_x2"], H, H, GL, GR) - g["A_dAC2"]).max() < 1e-11
+    assert np.abs(np.stack(mo.transfer_left(GL, H, g["A_A"], g["A_Ab"])) - g["A_tl"]).max() < 1e-12
+    assert np.abs(np.stack(mo.transfer_right(GR, H, g["A_A"], g["A_Ab"])) - g["A_tr"]).max() < 1e-12
+    q, r = mo.qrpos(g["G_M"])
+    assert np.abs(q - g["G_Q"]).max() < 1e-12 and np.abs(r - g["G_R"]).max() < 1e-12
