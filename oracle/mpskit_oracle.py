@@ -283,19 +283,23 @@ def dC(x, GL, GR):
 
 
 def dAC2(x, h1: SparseMPOSlice, h2: SparseMPOSlice, GL, GR):
-    """derivatives.jl:119-154; x[a, s1, b, s2] (V_l (x) P <- V_r (x) P)."""
+    """derivatives.jl:119-154; x[a, s1, b, s2] (V_l (x) P <- V_r (x) P); pairwise BLAS contractions."""
     hl = [None] * h1.odim
     for j in range(h1.odim):
         cur = None
         for i in h1.keys_col(j):
-            t = np.einsum("pwa,wtsu,asbr->ptbru", GL[i], h1.dense(i, j), x, optimize=True)
+            t1 = np.tensordot(GL[i], x, axes=([2], [0]))                           # [p, w, s, b, r]
+            t = np.tensordot(t1, h1.dense(i, j), axes=([1, 2], [0, 2]))            # [p, b, r, t, u]
+            t = np.transpose(t, (0, 3, 1, 2, 4))                                   # [p, t, b, r, u]
             cur = t if cur is None else cur + t
         hl[j] = cur
     out = None
     for (j, k) in h2.keys():
         if hl[j] is None:
             continue
-        t = np.einsum("ptbru,uzrv,bvq->ptqz", hl[j], h2.dense(j, k), GR[k], optimize=True)
+        t2 = np.tensordot(hl[j], h2.dense(j, k), axes=([3, 4], [2, 0]))            # [p, t, b, z, v]
+        t = np.tensordot(t2, GR[k], axes=([2, 4], [0, 1]))                         # [p, t, z, q]
+        t = np.transpose(t, (0, 1, 3, 2))                                          # [p, t, q, z]
         out = t if out is None else out + t
     return out
 

@@ -55,7 +55,11 @@ def test_full_size_properties(be):
     import torch
     import mpskit_jl_amd as mk
     D, d, W = 1024, 2, 5
-    H = mk.heisenberg_XXX(0.5, be=be)[0]
+    # 5-level slice with SYMMETRIC d x d blocks (Sz, Sx) so that symmetric environments give a
+    # symmetric effective Hamiltonian (the S+/S- blocks of heisenberg_XXX are each other's transpose)
+    Sz = np.diag([0.5, -0.5]); Sx = np.array([[0.0, 0.5], [0.5, 0.0]])
+    H = mk.MPOHamiltonian({(0, 0): 1.0, (4, 4): 1.0, (0, 1): Sz, (1, 4): Sz, (0, 2): Sx, (2, 4): Sx,
+                           (0, 3): 0.3 * Sz, (3, 4): Sx + Sz, (0, 4): 0.7 * Sx}, be=be)[0]
     g = torch.Generator(device="cpu").manual_seed(5)
     rnd = lambda *s: be.upload(torch.rand(*s, generator=g, dtype=torch.float64).numpy() - 0.5)
     # symmetric environments -> the effective Hamiltonian is symmetric: <u, H v> = <H u, v>
