@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--D", type=int, default=1024)
     ap.add_argument("--matvecs", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="run the sharded-matvec plumbing even with one rank (exercises the RCCL path on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -105,9 +107,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_shard:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import mpskit_jl_amd as mk
     from mpskit_jl_amd import algorithms as alg, krylov
@@ -122,7 +126,7 @@ def main():
     envs = mk.FinEnv(psi, H)
     eig = mk.Arnoldi(fixed_matvecs=args.matvecs, krylovdim=max(args.matvecs, 2))
     ws = krylov.KrylovWorkspace(be)
-    wrap = shard_wrapper(be, world, rank) if world > 1 else None
+    wrap = shard_wrapper(be, world, rank, force=args.force_shard) if (world > 1 or args.force_shard) else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -204,7 +208,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, D, d)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_shard:
         dist.destroy_process_group()
 
 

@@ -150,6 +150,10 @@ int mpsk_vzero(mpsk_ctx* ctx, int64_t n, void* x);
  *                    (coefficients stay on the device between the two kernels) */
 int mpsk_vmultidot(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const void* y, double* host_out);
 int mpsk_vgs_step(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* y, double* host_out);
+/*   mpsk_vorth_step: one full Krylov orthogonalisation step with a single host sync: CGS2 of y against
+ *                    xs[0..k), then y <- y / ||y||; host_h[j] = coefficient on xs[j], *host_beta = ||y|| */
+int mpsk_vorth_step(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* y, double* host_h,
+                    double* host_beta);
 /* y = sum_j coefs[j] xs[j]   (Ritz vector assembly) */
 int mpsk_vlincomb(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y);
 

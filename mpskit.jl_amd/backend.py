@@ -288,6 +288,14 @@ class Backend:
         check(self.lib.mpsk_vgs_step(self.ctx, y.size, len(xs), self._ptrs(xs), y.ptr, out), "mpsk_vgs_step")
         return np.array(out[:])
 
+    def orth_step(self, xs, y: DTensor):
+        """CGS2 of y against xs, then y <- y/||y||; ONE host sync.  Returns (h[k], beta)."""
+        out = (C.c_double * len(xs))()
+        beta = C.c_double()
+        check(self.lib.mpsk_vorth_step(self.ctx, y.size, len(xs), self._ptrs(xs), y.ptr, out, C.byref(beta)),
+              "mpsk_vorth_step")
+        return np.array(out[:]), beta.value
+
     def lincomb(self, xs, coefs, out: DTensor = None):
         y = self.empty(xs[0].shape) if out is None else out
         cf = (C.c_double * len(xs))(*[float(c) for c in coefs])

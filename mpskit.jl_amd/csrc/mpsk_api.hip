@@ -608,6 +608,29 @@ int mpsk_vgs_step(mpsk_ctx* c, int64_t n, int k, const void* const* xs, void* y,
   return fetch_scalars(c, k, host_out);
 }
 
+// One Krylov orthogonalisation step with ONE host sync: twice-iterated classical Gram-Schmidt of y
+// against xs[0..k), then y <- y / ||y||.  host_h[j] = total coefficient on xs[j], *host_beta = ||y||
+// before normalisation.  (KrylovKit's ModifiedGramSchmidt2 + normalize, 4 calls / 3 syncs fused.)
+int mpsk_vorth_step(mpsk_ctx* c, int64_t n, int k, const void* const* xs, void* y, double* host_h, double* host_beta) {
+  REQUIRE(c && xs && y && host_h && host_beta, "NULL argument");
+  REQUIRE(k > 0 && 2 * k + 1 <= MAXK && n > 0, "bad k or n");
+  HIPCHK(hipSetDevice(c->device));
+  const double* const* X = (const double* const*)xs;
+  double* yy = (double*)y;
+  HIPCHK(vec_multidot(X, k, yy, n, c->d_scal, c->d_partial, c->stream));
+  HIPCHK(vec_multiaxpy(X, c->d_scal, k, -1.0, yy, n, c->stream));
+  HIPCHK(vec_multidot(X, k, yy, n, c->d_scal + k, c->d_partial, c->stream));
+  HIPCHK(vec_multiaxpy(X, c->d_scal + k, k, -1.0, yy, n, c->stream));
+  const double* ys[1] = {yy};
+  HIPCHK(vec_multidot(ys, 1, yy, n, c->d_scal + 2 * k, c->d_partial, c->stream));
+  HIPCHK(vec_scal_rsqrt_dev(c->d_scal + 2 * k, yy, n, c->stream));
+  double tmp[MAXK];
+  if (int rc = fetch_scalars(c, 2 * k + 1, tmp)) return rc;
+  for (int j = 0; j < k; ++j) host_h[j] = tmp[j] + tmp[k + j];
+  *host_beta = tmp[2 * k] > 0.0 ? std::sqrt(tmp[2 * k]) : 0.0;
+  return MPSK_OK;
+}
+
 int mpsk_vlincomb(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y) {
   REQUIRE(c && xs && y && host_coefs, "NULL argument");
   REQUIRE(k > 0 && k <= MAXK && n > 0, "bad k or n");

@@ -49,66 +49,137 @@ __global__ __launch_bounds__(256) void cq_shift_kernel(double* __restrict__ G, i
   for (int i = threadIdx.x; i < n; i += 256) G[i + (int64_t)i * npad] += s;
 }
 
-// Cholesky (upper, G_kk = R^T R) and triangular inverse of one 64x64 diagonal block.
-// Thread (i0 = tid >> 6, l = tid & 63) keeps its 16 elements (rows i0 + 4k of column l) in
-// REGISTERS; per elimination step the owners publish the pivot row to a double-buffered LDS row
-// (one barrier per step, 17 independent LDS reads) -- an LDS-resident matrix with read-modify-write
-// per element is latency-bound (~120 us per block, profiles/r01), this form is ~10x faster.
-// Writes R_kk back into G (strict lower part zeroed) and R_kk^{-1} into Rinv's diagonal block.
-__global__ __launch_bounds__(256) void cq_potrf_diag_kernel(double* __restrict__ G, double* __restrict__ Rinv,
-                                                            int npad, int k, int* __restrict__ flag) {
-  __shared__ double S[CB][CB + 1];       // R (written once after the factorisation)
-  __shared__ double rowbuf[2][CB];
-  __shared__ double dsq[CB];
-  __shared__ double dinvd[CB];           // 1 / R[i][i]
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  const int l = tid & 63, i0 = tid >> 6;
+typedef double cq_d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double cq_readlane(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Cholesky (upper, G_kk = R^T R) of one 64x64 diagonal block on the MATRIX CORES: the block lives
+// in MFMA accumulators (4 waves x 2x2 tiles of 16x16); rows are eliminated four at a time:
+//   (a) the owners copy rows j0..j0+3 to LDS,  (b) wave 0 factors that 4 x 64 panel with
+//   cross-lane reads (lane = column),  (c) every wave applies the rank-4 update
+//   acc -= P^T P with v_mfma_f64_16x16x4_f64 (K = 4 is exactly the MFMA depth).
+// 16 chunks x 2 barriers instead of 64 latency-bound column steps (profiles/r01: 79 us -> ~10 us).
+// Writes R_kk over G_kk (strict lower part zeroed).
+__global__ __launch_bounds__(256) void cq_potrf64_mfma_kernel(double* __restrict__ G, int npad, int k,
+                                                              int* __restrict__ flag) {
+  __shared__ double P[2][4][CB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane >> 4, lc = lane & 15;
   double* Gk = G + (int64_t)k * CB * (npad + 1);
-  double* Rk = Rinv + (int64_t)k * CB * (npad + 1);
-  if (tid == 0) bad = 0;
-  double a[CB / 4];
+  cq_d4 acc[2][2];
 #pragma unroll
-  for (int kk = 0; kk < CB / 4; ++kk) a[kk] = Gk[(i0 + 4 * kk) + (int64_t)l * npad];
-  for (int j = 0; j < CB; ++j) {
-    if (i0 == (j & 3)) {                 // owners of row j publish it (unscaled)
-      double v = 0.0;
+  for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-      for (int kk = 0; kk < CB / 4; ++kk) if (kk == (j >> 2)) v = a[kk];
-      rowbuf[j & 1][l] = v;
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        acc[ti][tj][rg] = Gk[(32 * wr + 16 * ti + lr + 4 * rg) + (int64_t)(32 * wc + 16 * tj + lc) * npad];
+  int bad = 0;
+  for (int c = 0; c < CB / 4; ++c) {
+    const int j0 = 4 * c;
+    double (*Pb)[CB] = P[c & 1];
+    if (wr == (j0 >> 5)) {                 // (a) rows j0 + lr live in tile row ti, register q
+      const int ti = (j0 >> 4) & 1, q = (j0 >> 2) & 3;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const cq_d4 v = ti ? acc[1][tj] : acc[0][tj];
+        const double e = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
+        Pb[lr][32 * wc + 16 * tj + lc] = e;
+      }
     }
     __syncthreads();
-    const double* rb = rowbuf[j & 1];
-    const double piv = rb[j];
-    const bool ok = (piv > 0.0) && isfinite(piv);
-    const double dinv2 = ok ? 1.0 / piv : 0.0;
-    if (tid == 0) { const double sq = ok ? sqrt(piv) : 1.0; dsq[j] = sq; dinvd[j] = 1.0 / sq; if (!ok) bad = 1; }
-    const double sjl = rb[l] * dinv2;
-    double rv[CB / 4];                   // issue all LDS reads back-to-back (one wait), then branch-free math
+    if (wave == 0) {                       // (b) 4 x 64 panel, lane = column
+      double p[4];
 #pragma unroll
-    for (int kk = 0; kk < CB / 4; ++kk) rv[kk] = rb[i0 + 4 * kk];
+      for (int t = 0; t < 4; ++t) p[t] = Pb[t][lane];
 #pragma unroll
-    for (int kk = 0; kk < CB / 4; ++kk) {
-      const int i = i0 + 4 * kk;
-      const double upd = rv[kk] * sjl;
-      a[kk] -= (i > j && i <= l) ? upd : 0.0;
+      for (int t = 0; t < 4; ++t) {
+        const double piv = cq_readlane(p[t], j0 + t);
+        const bool ok = (piv > 0.0) && (piv < 1.0e300);
+        if (!ok) bad = 1;
+        const double sq = ok ? sqrt(piv) : 1.0;
+        const double rs = ok ? 1.0 / sq : 0.0;
+        p[t] = (lane > j0 + t) ? p[t] * rs : (lane == j0 + t ? sq : 0.0);
+#pragma unroll
+        for (int u = t + 1; u < 4; ++u) {
+          const double r = cq_readlane(p[t], j0 + u);
+          p[u] -= r * p[t];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        Pb[t][lane] = p[t];
+        Gk[(j0 + t) + (int64_t)lane * npad] = p[t];
+      }
     }
-  }
-  __syncthreads();
-  // R[i][l] = a / dsq[i] (i < l), dsq[i] on the diagonal, 0 below
+    __syncthreads();
+    double af[2], bf[2];                   // (c) rank-4 update on the matrix cores
 #pragma unroll
-  for (int kk = 0; kk < CB / 4; ++kk) {
-    const int i = i0 + 4 * kk;
-    const double r = (i < l) ? a[kk] * dinvd[i] : (i == l ? dsq[i] : 0.0);
-    S[i][l] = r;
-    Gk[i + (int64_t)l * npad] = r;
+    for (int ti = 0; ti < 2; ++ti) af[ti] = -Pb[lr][32 * wr + 16 * ti + lc];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) bf[tj] = Pb[lr][32 * wc + 16 * tj + lc];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
   }
+  if (wave == 0 && lane == 0 && bad) atomicOr(flag, 1);
+}
+
+// panel (64 x rest, ld npad)  <-  R_kk^{-T} panel : forward substitution, one thread per column with the
+// column in registers and R_kk broadcast from LDS (fully unrolled: 2016 FMAs per thread).
+__global__ __launch_bounds__(256) void cq_trsm_panel_kernel(const double* __restrict__ Rkk, double* __restrict__ panel,
+                                                            int npad, int rest) {
+  __shared__ double Rc[CB][CB];            // Rc[i][l] = R[l][i]  (column i contiguous in l)
+  __shared__ double dinv[CB];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int l = e & 63, i = e >> 6;
+    Rc[i][l] = Rkk[l + (int64_t)i * npad];
+  }
+  if (tid < CB) dinv[tid] = 1.0 / Rkk[tid + (int64_t)tid * npad];
   __syncthreads();
-  // inverse: x[kk] = Y[i0 + 4kk][c] (unscaled rows), step i: xi = Y[i][c] / R[i][i], rows above -= R[r][i] xi
-  const int c = l;
+  const int col = blockIdx.x * 256 + tid;
+  if (col >= rest) return;
+  double* pc = panel + (int64_t)col * npad;
+  double x[CB];
+#pragma unroll
+  for (int i = 0; i < CB; ++i) x[i] = pc[i];
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    double s = x[i];
+#pragma unroll
+    for (int l = 0; l < i; ++l) s -= Rc[i][l] * x[l];
+    x[i] = s * dinv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) pc[i] = x[i];
+}
+
+// Rinv diagonal blocks (all at once, off the critical path): inverse of each upper-triangular R_bb.
+// Thread (i0 = tid >> 6, c = tid & 63) keeps rows i0 + 4k of column c of the inverse in registers;
+// step i reads row i only (x_i = Y[i][c] / R[i][i]) and updates the rows above it.
+__global__ __launch_bounds__(256) void cq_diag_inverse_kernel(const double* __restrict__ R, double* __restrict__ Rinv,
+                                                              int npad) {
+  __shared__ double S[CB][CB + 1];
+  __shared__ double rowbuf[2][CB];
+  __shared__ double dinvd[CB];
+  const int tid = threadIdx.x, c = tid & 63, i0 = tid >> 6;
+  const double* Rb = R + (int64_t)blockIdx.x * CB * (npad + 1);
+  double* Xb = Rinv + (int64_t)blockIdx.x * CB * (npad + 1);
+  for (int e = tid; e < CB * CB; e += 256) S[e & 63][e >> 6] = Rb[(e & 63) + (int64_t)(e >> 6) * npad];
+  __syncthreads();
+  if (tid < CB) dinvd[tid] = 1.0 / S[tid][tid];
   double x[CB / 4];
 #pragma unroll
   for (int kk = 0; kk < CB / 4; ++kk) x[kk] = ((i0 + 4 * kk) == c) ? 1.0 : 0.0;
+  __syncthreads();
   for (int i = CB - 1; i >= 0; --i) {
     if (i0 == (i & 3)) {
       double v = 0.0;
@@ -131,9 +202,8 @@ __global__ __launch_bounds__(256) void cq_potrf_diag_kernel(double* __restrict__
 #pragma unroll
   for (int kk = 0; kk < CB / 4; ++kk) {
     const int r = i0 + 4 * kk;
-    Rk[r + (int64_t)c * npad] = (r <= c) ? x[kk] * dinvd[r] : 0.0;
+    Xb[r + (int64_t)c * npad] = (r <= c) ? x[kk] * dinvd[r] : 0.0;
   }
-  if (tid == 0 && bad) atomicOr(flag, 1);
 }
 
 // zero everything outside the block upper triangle of R (garbage of the trailing updates) and
@@ -191,19 +261,19 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
   }
   const int nb = npad / CB;
   for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(cq_potrf_diag_kernel, dim3(1), dim3(256), 0, s, Rp, Rinv, npad, k, flag);
+    hipLaunchKernelGGL(cq_potrf64_mfma_kernel, dim3(1), dim3(256), 0, s, Rp, npad, k, flag);
     const int rest = npad - (k + 1) * CB;
     if (rest <= 0) break;
     double* panel = Rp + (int64_t)k * CB + (int64_t)(k + 1) * CB * npad;     // rows k-block, cols > k-block
-    const double* Rik = Rinv + (int64_t)k * CB * (npad + 1);
-    // panel <- R_kk^{-T} panel  (in place: one 64-row tile reads all of its K rows before it writes)
-    g = cq_mk(Rik, panel, panel, CB, rest, CB, npad, npad, npad, 1, 1.0, 0.0);
-    if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+    const double* Rkk = Rp + (int64_t)k * CB * (npad + 1);
+    // panel <- R_kk^{-T} panel
+    hipLaunchKernelGGL(cq_trsm_panel_kernel, dim3((rest + 255) / 256), dim3(256), 0, s, Rkk, panel, npad, rest);
     // trailing -= panel^T panel
     double* trail = Rp + (int64_t)(k + 1) * CB * (npad + 1);
     g = cq_mk(panel, panel, trail, rest, rest, CB, npad, npad, npad, 1, -1.0, 1.0);
     if ((e = gemm_f64(g, s)) != hipSuccess) return e;
   }
+  hipLaunchKernelGGL(cq_diag_inverse_kernel, dim3(nb), dim3(256), 0, s, Rp, Rinv, npad);
   hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
   // R^{-1} by recursive doubling: inv([R11 R12; 0 R22]) = [i11, -i11 R12 i22; 0, i22]
   for (int b = CB; b < npad; b <<= 1) {

@@ -230,6 +230,22 @@ __global__ __launch_bounds__(256) void scal_kernel(double a, double* x, int64_t 
     x[e] *= a;
 }
 
+// x *= 1/sqrt(*d_n2)  (scale factor stays on the device; 0 if the squared norm is not positive)
+__global__ __launch_bounds__(256) void scal_rsqrt_dev_kernel(const double* __restrict__ d_n2, double* x, int64_t n) {
+  const double n2 = *d_n2;
+  const double a = (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    x[e] *= a;
+}
+
+hipError_t vec_scal_rsqrt_dev(const double* d_n2, double* x, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(scal_rsqrt_dev_kernel, dim3((int)nb), dim3(256), 0, s, d_n2, x, n);
+  return hipGetLastError();
+}
+
 hipError_t vec_scal(double a, double* x, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   int64_t nb = (n + 255) / 256;

@@ -35,8 +35,8 @@ class BondShard:
         return self.lo + self.block
 
     @staticmethod
-    def shardable(D, world, min_block=64):
-        return world > 1 and D % world == 0 and D // world >= min_block
+    def shardable(D, world, min_block=64, force=False):
+        return (world > 1 or force) and D % world == 0 and D // world >= min_block
 
 
 class HostPlumbing:
@@ -112,14 +112,14 @@ class ShardedMatvec:
         return y
 
 
-def shard_wrapper(be, world, rank, group=None, min_block=64):
+def shard_wrapper(be, world, rank, group=None, min_block=64, force=False):
     """Returns wrap(h: MPO_ddAC) -> callable used by dmrg_sweep: sites whose bond dimension is
     shardable run the sharded matvec, the others (chain edges) run replicated."""
     pl = DevicePlumbing(be)
 
     def wrap(h):
         D = h.leftenv.shape[1]
-        if not BondShard.shardable(D, world, min_block):
+        if not BondShard.shardable(D, world, min_block, force):
             return h
         return ShardedMatvec(pl, h.o, h.leftenv, h.rightenv, world, rank, group)
     return wrap

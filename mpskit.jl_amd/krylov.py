@@ -1,7 +1,8 @@
 """Host-side Krylov solvers on DEVICE vectors (the KrylovKit role in the reference:
 src/algorithms/fixedpoint.jl:9-30, mpohaminfenv.jl:95).  The loop stays on the host, every
 matvec is one call into libmpsk, and the Gram-Schmidt step is the fused multi-dot / multi-axpy
-pair `mpsk_vgs_step` (coefficients never leave the device between the two kernels).
+pair fused with the normalisation in `mpsk_vorth_step` (coefficients stay on the device, ONE host sync
+per Krylov iteration).
 """
 from __future__ import annotations
 
@@ -47,9 +48,8 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
             w = V[k + 1]
             matvec(V[k], w)
             nmv += 1
-            for _ in range(2):
-                Hm[:k + 1, k] += be.gs_step(V[:k + 1], w)
-            beta = be.norm(w)
+            h, beta = be.orth_step(V[:k + 1], w)      # CGS2 + normalise, one host sync
+            Hm[:k + 1, k] = h
             Hm[k + 1, k] = beta
             k += 1
             Hk = Hm[:k, :k]
@@ -60,8 +60,6 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
             if (fixed_matvecs is None and res < tol) or beta < 1e-300 or done_fixed:
                 conv = True
                 break
-            if k < krylovdim:
-                be.scal(1.0 / beta, w)
         be.lincomb(V[:k], s, out=ritz)
         start = ritz
         if conv:
@@ -91,9 +89,8 @@ def eigsolve_lm_real(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, 
         while k < krylovdim:
             w = V[k + 1]
             matvec(V[k], w)
-            for _ in range(2):
-                Hm[:k + 1, k] += be.gs_step(V[:k + 1], w)
-            beta = be.norm(w)
+            h, beta = be.orth_step(V[:k + 1], w)
+            Hm[:k + 1, k] = h
             Hm[k + 1, k] = beta
             k += 1
             ev, S = np.linalg.eig(Hm[:k, :k])
@@ -105,8 +102,6 @@ def eigsolve_lm_real(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, 
             if res < tol or beta < 1e-300:
                 conv = True
                 break
-            if k < krylovdim:
-                be.scal(1.0 / beta, w)
         be.lincomb(V[:k], s, out=ritz)
         start = ritz
         if conv:
@@ -143,9 +138,8 @@ def gmres(be: Backend, matvec, b: DTensor, x0: DTensor, tol=1e-12, krylovdim=30,
         while k < krylovdim:
             w = V[k + 1]
             matvec(V[k], w)
-            for _ in range(2):
-                Hm[:k + 1, k] += be.gs_step(V[:k + 1], w)
-            hn = be.norm(w)
+            h, hn = be.orth_step(V[:k + 1], w)
+            Hm[:k + 1, k] = h
             Hm[k + 1, k] = hn
             k += 1
             e1 = np.zeros(k + 1)
@@ -154,8 +148,6 @@ def gmres(be: Backend, matvec, b: DTensor, x0: DTensor, tol=1e-12, krylovdim=30,
             res = np.linalg.norm(Hm[:k + 1, :k] @ y - e1)
             if res <= tol or hn < 1e-300:
                 break
-            if k < krylovdim:
-                be.scal(1.0 / hn, w)
         be.lincomb(V[:k], y, out=tmp)
         be.axpby(1.0, tmp, 1.0, x)
         if res <= tol:

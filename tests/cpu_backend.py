@@ -211,6 +211,14 @@ class CpuBackend:
         y.buf[: y.size] = torch.from_numpy(np.ascontiguousarray(v))
         return h
 
+    def orth_step(self, xs, y):
+        h = self.gs_step(xs, y)
+        h = h + self.gs_step(xs, y)
+        beta = self.norm(y)
+        if beta > 0:
+            self.scal(1.0 / beta, y)
+        return h, beta
+
     def lincomb(self, xs, coefs, out=None):
         y = self.empty(xs[0].shape) if out is None else out
         v = sum(float(c) * self._v(x) for c, x in zip(coefs, xs))
