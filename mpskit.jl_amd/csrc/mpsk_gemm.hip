@@ -180,7 +180,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
       for (int rg = 0; rg < 4; ++rg) {
         const int n = n0 + wn * WTN + j * 16 + fq + 4 * rg;
         if (ALIGNED || (m < g.M && n < g.N)) {
-          double* p = Cb + m + (int64_t)n * g.ldc;
+          double* p = (g.tabC2 != nullptr && n >= g.splitN)
+                          ? g.C + g.tabC2[z] + m + (int64_t)(n - g.splitN) * g.ldc
+                          : Cb + m + (int64_t)n * g.ldc;
           double v = alpha * acc[i][j][rg];
           if (beta != 0.0) v += beta * (*p);
           *p = v;

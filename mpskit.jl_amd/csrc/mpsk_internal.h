@@ -26,6 +26,9 @@ struct GemmArgs {
   const int64_t* tabA;
   const int64_t* tabB;
   const int64_t* tabC;
+  // optional column split of C: columns n >= splitN of batch z go to C + tabC2[z] + (n - splitN)*ldc
+  const int64_t* tabC2;
+  int splitN;
   int tag;                   // 1: matvec-stage launch (own kernel symbol + event profile)
   int tabs_even;             // caller guarantees every tabA/tabB entry is even (16-B aligned operands)
 };

@@ -78,7 +78,13 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
   }
   __syncthreads();
 
-  for (int sweep = 0; sweep < 40; ++sweep) {
+  // Two inner sweeps per visit are enough: the outer block-Jacobi iteration converges anyway and
+  // its rotations become tiny (quadratic convergence); a full inner diagonalisation (6-8 sweeps of
+  // 63 latency-bound steps) made this kernel ~2 ms per round (profiles/r01_other_configs.log).
+  // Thread (k = tid >> 3, j = tid & 7) owns pair k and rows/columns j + 8 i: all LDS reads of a phase
+  // are issued before the arithmetic (one latency, not eight).
+  const int pk = tid >> 3, pj = tid & 7;
+  for (int sweep = 0; sweep < 2; ++sweep) {
     if (tid == 0) any_rot = 0;
     __syncthreads();
     for (int st = 0; st < J2 - 1; ++st) {
@@ -99,31 +105,40 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
         cs_c[tid] = c; cs_s[tid] = s; cs_p[tid] = pp; cs_q[tid] = qq;
       }
       __syncthreads();
-      // columns:  M <- M J,  W <- W J
-      for (int e = tid; e < (J2 / 2) * J2; e += 256) {
-        const int k = e / J2, r = e % J2;
-        const double c = cs_c[k], s = cs_s[k];
-        const int pp = cs_p[k], qq = cs_q[k];
-        const double mp = Ms[r][pp], mq = Ms[r][qq];
-        Ms[r][pp] = c * mp - s * mq;
-        Ms[r][qq] = s * mp + c * mq;
-        const double wp = Ws[r][pp], wq = Ws[r][qq];
-        Ws[r][pp] = c * wp - s * wq;
-        Ws[r][qq] = s * wp + c * wq;
+      const double c = cs_c[pk], sn = cs_s[pk];
+      const int pp = cs_p[pk], qq = cs_q[pk];
+      {   // columns:  M <- M J,  W <- W J
+        double mp[8], mq[8], wp[8], wq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = pj + 8 * i;
+          mp[i] = Ms[r][pp]; mq[i] = Ms[r][qq]; wp[i] = Ws[r][pp]; wq[i] = Ws[r][qq];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = pj + 8 * i;
+          Ms[r][pp] = c * mp[i] - sn * mq[i];
+          Ms[r][qq] = sn * mp[i] + c * mq[i];
+          Ws[r][pp] = c * wp[i] - sn * wq[i];
+          Ws[r][qq] = sn * wp[i] + c * wq[i];
+        }
       }
       __syncthreads();
-      // rows:  M <- J^T M
-      for (int e = tid; e < (J2 / 2) * J2; e += 256) {
-        const int k = e / J2, r = e % J2;
-        const double c = cs_c[k], s = cs_s[k];
-        const int pp = cs_p[k], qq = cs_q[k];
-        const double mp = Ms[pp][r], mq = Ms[qq][r];
-        Ms[pp][r] = c * mp - s * mq;
-        Ms[qq][r] = s * mp + c * mq;
-      }
-      __syncthreads();
-      if (tid < J2 / 2) {   // the rotated off-diagonal entry is exactly annihilated
-        if (cs_s[tid] != 0.0) { Ms[cs_p[tid]][cs_q[tid]] = 0.0; Ms[cs_q[tid]][cs_p[tid]] = 0.0; }
+      {   // rows:  M <- J^T M ; the rotated off-diagonal entry is set to exactly zero
+        double mp[8], mq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = pj + 8 * i;
+          mp[i] = Ms[pp][r]; mq[i] = Ms[qq][r];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = pj + 8 * i;
+          double vp = c * mp[i] - sn * mq[i], vq = sn * mp[i] + c * mq[i];
+          if (sn != 0.0) { if (r == qq) vp = 0.0; if (r == pp) vq = 0.0; }
+          Ms[pp][r] = vp;
+          Ms[qq][r] = vq;
+        }
       }
       __syncthreads();
     }
@@ -272,13 +287,14 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       hgA[p * Q + q] = (int64_t)p * J2 * mm + (int64_t)q * kq;
       hgC[p * Q + q] = ((int64_t)p * Q + q) * J2 * J2;
     }
-    for (int hf = 0; hf < 2; ++hf) {
-      huAG[2 * p + hf] = (int64_t)p * J2 * mm;
-      huAV[2 * p + hf] = (int64_t)p * J2 * nn;
-      huB[2 * p + hf] = (int64_t)p * J2 * J2 + (int64_t)hf * JB * J2;
-      huCG[2 * p + hf] = (int64_t)dest_slot(p, hf) * JB * mm;
-      huCV[2 * p + hf] = (int64_t)dest_slot(p, hf) * JB * nn;
-    }
+    // update tables, one entry per pair: entries [0, P) = first half's destination, [P, 2P) = second half's
+    huAG[p] = (int64_t)p * J2 * mm;
+    huAV[p] = (int64_t)p * J2 * nn;
+    huB[p] = (int64_t)p * J2 * J2;
+    huCG[p] = (int64_t)dest_slot(p, 0) * JB * mm;
+    huCG[P + p] = (int64_t)dest_slot(p, 1) * JB * mm;
+    huCV[p] = (int64_t)dest_slot(p, 0) * JB * nn;
+    huCV[P + p] = (int64_t)dest_slot(p, 1) * JB * nn;
   }
   hipError_t e;
   if ((e = hipMemcpyAsync(tabs, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
@@ -307,11 +323,13 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       // 3. updates into next round's slots
       GemmArgs u;
       std::memset(&u, 0, sizeof(u));
-      u.B = Wm; u.N = JB; u.K = J2; u.ldb = J2; u.batch = 2 * P; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
-      u.tabB = t_updB; u.tabs_even = kq_even;
+      u.B = Wm; u.N = J2; u.K = J2; u.ldb = J2; u.batch = P; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
+      u.tabB = t_updB; u.tabs_even = kq_even; u.splitN = JB;
       u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G; u.tabC = t_updC_G;
+      u.tabC2 = t_updC_G + P;
       if ((e = gemm_f64(u, s)) != hipSuccess) return e;
       u.A = V[cur]; u.C = V[cur ^ 1]; u.M = nn; u.lda = nn; u.ldc = nn; u.tabA = t_updA_V; u.tabC = t_updC_V;
+      u.tabC2 = t_updC_V + P;
       if ((e = gemm_f64(u, s)) != hipSuccess) return e;
       cur ^= 1;
     }

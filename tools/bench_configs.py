@@ -1,0 +1,79 @@
+"""Secondary measurements for the other BASELINE.json configs (not the bench.py line):
+  c2  Heisenberg S=1 FiniteMPS L=100 D=256, 1-site DMRG sweep (fixed Krylov budget 8)
+  c3  transverse-field Ising InfiniteMPS D=512, VUMPS iterations (dAC/dC eigsolves + gauge + envs)
+  c4  Hubbard FiniteMPS D=1024-class two-site update: dAC2 matvec + tsvd at (D*d) x (d*D) (reduced L)
+usage: python tools/bench_configs.py [c2] [c3] [c4] [tsvd]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import mpskit_jl_amd as mk
+from mpskit_jl_amd import algorithms as alg, krylov
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def c2(be):
+    L, D, d = 100, 256, 3
+    H = mk.heisenberg_XXX(1.0, be=be)
+    psi = mk.FiniteMPS.random(L, d, D, np.random.default_rng(1), be=be)
+    envs = mk.FinEnv(psi, H)
+    eig = mk.Arnoldi(fixed_matvecs=8, krylovdim=8)
+    ws = krylov.KrylovWorkspace(be)
+    alg.dmrg_sweep(psi, H, envs, eig, ws)
+    sync(); t0 = time.perf_counter()
+    for _ in range(2):
+        alg.dmrg_sweep(psi, H, envs, eig, ws)
+    sync(); dt = (time.perf_counter() - t0) / 2
+    print(f"c2 Heisenberg S=1 L=100 D=256 d=3: {dt:.3f} s/sweep = {1 / dt:.3f} sweeps/s", flush=True)
+
+
+def c3(be):
+    D = 512
+    H = mk.transverse_field_ising(1.0, 0.5, be=be)
+    psi = mk.InfiniteMPS.random(2, D, np.random.default_rng(2), be=be)
+    sync(); t0 = time.perf_counter()
+    p, e, eps = mk.find_groundstate(psi, H, mk.VUMPS(tol=1e-10, maxiter=6, verbosity=3))
+    sync(); dt = time.perf_counter() - t0
+    E = float(np.sum(mk.expectation_value(p, H, e)))
+    print(f"c3 VUMPS iTFI D=512: 6 iterations in {dt:.2f} s ({dt / 6:.2f} s/iter), e = {E:.12f}, galerkin = {eps:.2e}", flush=True)
+
+
+def c4(be):
+    D, d = 1024, 4
+    H = mk.hubbard(1.0, 4.0, be=be)
+    W = H[0].Wl
+    r = lambda *s: mk.DTensor(torch.rand(int(np.prod(s)), dtype=torch.float64, device=be.device) - 0.5, s)
+    GL, GR = r(W, D, D), r(W, D, D)
+    x2, y2 = r(D, d, D, d), be.empty(D, d, D, d)
+    be.dAC2(H[0], H[0], GL, GR, x2, out=y2)
+    sync(); t0 = time.perf_counter()
+    for _ in range(3):
+        be.dAC2(H[0], H[0], GL, GR, x2, out=y2)
+    sync(); dt = (time.perf_counter() - t0) / 3
+    fl = 4 * W * d * d * D ** 3 + 4 * W * W * d ** 3 * D * D
+    print(f"c4 dAC2 D=1024 d=4 W=6: {dt * 1e3:.2f} ms = {fl / dt / 1e12:.1f} TFLOP/s (algorithmic {fl / 1e9:.0f} GF)", flush=True)
+
+
+def tsvd(be):
+    for n in (512, 1024, 2048, 4096):
+        A = mk.DTensor(torch.rand(n * n, dtype=torch.float64, device=be.device), (n, n))
+        sync(); t0 = time.perf_counter()
+        U, S, Vh, kept, disc = be.tsvd(A, max_keep=n // 4)
+        sync(); dt = time.perf_counter() - t0
+        print(f"tsvd {n}x{n} keep {n // 4}: {dt * 1e3:.1f} ms", flush=True)
+
+
+def main():
+    be = mk.Backend(0)
+    which = sys.argv[1:] or ["c2", "c3", "c4", "tsvd"]
+    for w in which:
+        globals()[w](be)
+
+
+main()
