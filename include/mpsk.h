@@ -119,6 +119,10 @@ int mpsk_regularize(mpsk_ctx* ctx, int W, int D1, int D2, void* v, const void* l
  * call sites: src/states/orthoview.jl:52,56 ; finitemps.jl:149 ; ortho.jl:128-136 ; dmrg.jl:96 */
 /* A (m x n, m >= n, lda) = Q (m x n, ldq) * R (n x n upper, ldr), diag(R) > 0.  A is not modified. */
 int mpsk_qrpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr);
+/* two independent QRpos of equal shape issued together (two streams inside the ctx): the sweep needs
+ * leftorth of the old AC (toolbox.jl:17-22) and of the new AC (orthoview.jl:56) at the same moment */
+int mpsk_qrpos2(mpsk_ctx* ctx, int m, int n, const void* A1, int lda1, void* Q1, int ldq1, void* R1, int ldr1,
+                const void* A2, int lda2, void* Q2, int ldq2, void* R2, int ldr2);
 /* A (m x n, m <= n) = L (m x m lower) * Q (m x n), diag(L) > 0 */
 int mpsk_lqpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq);
 /* thin SVD of theta (m x n): theta = U diag(S) Vh, S descending.  U: m x kmax, S: kmax, Vh: kmax x n

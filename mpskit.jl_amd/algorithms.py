@@ -77,6 +77,17 @@ def fixedpoint(be, A, x0, alg: Arnoldi, ws=None):
 
 # ---- measurements ------------------------------------------------------------------------------
 
+def _galerkin(be, h, ac, al):
+    """|| (1 - AL AL^dag) normalize(h(AC)) ||  for explicit tensors."""
+    g = h(ac)
+    be.scal(1.0 / be.norm(g), g)
+    Dl, d, Dr = al.shape
+    alm, gm = al.reshape(Dl * d, Dr), g.reshape(Dl * d, g.shape[2])
+    t = be.gemm(alm, gm, transA=True)
+    be.gemm(alm, t, alpha=-1.0, beta=1.0, out=gm)
+    return be.norm(gm)
+
+
 def calc_galerkin(psi, pos, envs, h=None):
     """|| (1 - AL AL^dag) normalize(H_AC AC) ||   (toolbox.jl:17-22).
     h: the site's effective Hamiltonian if the caller already built it (same operator)."""
@@ -87,13 +98,7 @@ def calc_galerkin(psi, pos, envs, h=None):
         ac, al = psi.AC[pos], psi.AL[pos]
     if h is None:
         h = ddAC(pos, psi, envs.H, envs)
-    g = h(ac)
-    be.scal(1.0 / be.norm(g), g)
-    Dl, d, Dr = al.shape
-    alm, gm = al.reshape(Dl * d, Dr), g.reshape(Dl * d, g.shape[2])
-    t = be.gemm(alm, gm, transA=True)
-    be.gemm(alm, t, alpha=-1.0, beta=1.0, out=gm)
-    return be.norm(gm)
+    return _galerkin(be, h, ac, al)
 
 
 def expectation_value(psi, H, envs):
@@ -155,9 +160,16 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None, wrap=None):
         h = ddAC(pos, psi, H, envs)
         if wrap is not None:
             h = wrap(h)
-        _, vec = fixedpoint(be, h, psi.AC(pos), eigalg, ws)
-        eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs, h=h))
-        psi.set_AC(pos, vec)
+        ac_old = psi.AC(pos)
+        _, vec = fixedpoint(be, h, ac_old, eigalg, ws)
+        if psi.ALs[pos] is None:
+            # right-moving visit: leftorth(old AC) (galerkin projector) and leftorth(new AC) (next AL)
+            # are both due -> issue them together; same state as the lazy views would produce
+            al_old = psi.set_AC_with_leftorth(pos, vec)
+            eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old))
+        else:
+            eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs, h=h))
+            psi.set_AC(pos, vec)
     return eps_s
 
 

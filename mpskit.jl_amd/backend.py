@@ -239,6 +239,15 @@ class Backend:
         check(self.lib.mpsk_qrpos(self.ctx, m, n, A.ptr, m, Q.ptr, m, R.ptr, k), "mpsk_qrpos")
         return Q, R
 
+    def qrpos2(self, A1: DTensor, A2: DTensor):
+        """two QRpos of equal shape in flight together (two streams inside the ctx)."""
+        m, n = A1.shape
+        assert A2.shape == (m, n) and m >= n
+        Q1, R1, Q2, R2 = self.empty(m, n), self.empty(n, n), self.empty(m, n), self.empty(n, n)
+        check(self.lib.mpsk_qrpos2(self.ctx, m, n, A1.ptr, m, Q1.ptr, m, R1.ptr, n, A2.ptr, m, Q2.ptr, m, R2.ptr, n),
+              "mpsk_qrpos2")
+        return Q1, R1, Q2, R2
+
     def lqpos(self, A: DTensor):
         m, n = A.shape
         k = min(m, n)

@@ -47,6 +47,12 @@ struct mpsk_ctx {
   int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
   int* d_flag = nullptr;
   long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0;
+  // second stream + workspace for two concurrent factorizations (mpsk_qrpos2)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void* ws2 = nullptr;
+  size_t ws2_bytes = 0;
+  int* h_flags = nullptr;       // pinned [2]
   std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
 };
 constexpr int MAXK = 256;
@@ -72,6 +78,10 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
   HIPCHK(hipMalloc(&c->d_partial, sizeof(double) * MPSK_DOT_SCRATCH));
   HIPCHK(hipHostMalloc(&c->h_scal, sizeof(double) * MAXK, hipHostMallocDefault));
   HIPCHK(hipMalloc(&c->d_flag, 64));
+  HIPCHK(hipHostMalloc(&c->h_flags, 64, hipHostMallocDefault));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   *out = c;
   return MPSK_OK;
 }
@@ -86,6 +96,11 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->d_flag) (void)hipFree(c->d_flag);
+  if (c->h_flags) (void)hipHostFree(c->h_flags);
+  if (c->ws2) (void)hipFree(c->ws2);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
   return MPSK_OK;
 }
@@ -513,6 +528,64 @@ int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int l
   HIPCHK(hipSetDevice(c->device));
   if (int rc = ensure_ws(c, sizeof(double) * qr_ws_doubles(m, n))) return rc;
   return qrpos_dispatch(c, m, n, (const double*)A, lda, (double*)Q, ldq, (double*)R, ldr, (double*)c->ws);
+}
+
+// Two independent QRpos factorizations of equal shape, in flight together on two streams (the
+// CholeskyQR3 launch chain is latency-bound, so the two chains interleave on the GPU): the DMRG sweep
+// needs leftorth of the OLD AC (galerkin projector, toolbox.jl:17-22) and of the NEW AC (next site's
+// AL, orthoview.jl:56) at the same moment.
+int mpsk_qrpos2(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1, int ldq1, void* R1, int ldr1,
+                const void* A2, int lda2, void* Q2, int ldq2, void* R2, int ldr2) {
+  REQUIRE(c && A1 && Q1 && R1 && A2 && Q2 && R2, "NULL argument");
+  REQUIRE(m >= n && n > 0, "needs m >= n > 0");
+  REQUIRE(lda1 >= m && ldq1 >= m && ldr1 >= n && lda2 >= m && ldq2 >= m && ldr2 >= n, "leading dimension too small");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t wsd = qr_ws_doubles(m, n);
+  if (int rc = ensure_ws(c, sizeof(double) * wsd)) return rc;
+  if (c->qr_mode == 1 || n <= 64) {
+    if (int rc = qrpos_dispatch(c, m, n, (const double*)A1, lda1, (double*)Q1, ldq1, (double*)R1, ldr1, (double*)c->ws)) return rc;
+    return qrpos_dispatch(c, m, n, (const double*)A2, lda2, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws);
+  }
+  if (c->ws2_bytes < sizeof(double) * wsd) {
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    if (c->ws2) HIPCHK(hipFree(c->ws2));
+    c->ws2 = nullptr; c->ws2_bytes = 0;
+    if (hipMalloc(&c->ws2, sizeof(double) * wsd) != hipSuccess) return fail(MPSK_ERR_NOMEM, "mpsk_qrpos2: workspace hipMalloc failed");
+    c->ws2_bytes = sizeof(double) * wsd;
+  }
+  // fork: stream2 sees everything enqueued on the main stream so far (A2 / Q2 / R2 allocations and producers)
+  HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  c->h_flags[0] = c->h_flags[1] = 0;
+  hipError_t e = cholqr3_enqueue(m, n, (const double*)A1, lda1, (double*)Q1, ldq1, (double*)R1, ldr1, (double*)c->ws,
+                                 c->d_flag, &c->h_flags[0], c->stream);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 (1): ") + hipGetErrorString(e));
+  e = cholqr3_enqueue(m, n, (const double*)A2, lda2, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws2,
+                      c->d_flag + 8, &c->h_flags[1], c->stream2);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 (2): ") + hipGetErrorString(e));
+  e = cholqr3_finalize(m, n, (double*)Q1, ldq1, (double*)R1, ldr1, (double*)c->ws, c->d_flag, &c->h_flags[0], c->stream);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 finalize (1): ") + hipGetErrorString(e));
+  e = cholqr3_finalize(m, n, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws2, c->d_flag + 8, &c->h_flags[1], c->stream2);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 finalize (2): ") + hipGetErrorString(e));
+  // join: later work on the main stream is ordered after stream2 (already drained by finalize)
+  HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  const int f1 = c->h_flags[0], f2 = c->h_flags[1];
+  if (f1 == 0) c->n_qr_chol++;
+  if (f2 == 0) c->n_qr_chol++;
+  if ((f1 != 0 || f2 != 0) && c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
+  std::string err;
+  if (f1 != 0) {
+    c->n_qr_fallback++; c->n_qr_house++;
+    hipError_t e2 = qrpos(m, n, (const double*)A1, lda1, (double*)Q1, ldq1, (double*)R1, ldr1, (double*)c->ws, c->stream, &err);
+    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (1) failed");
+  }
+  if (f2 != 0) {
+    c->n_qr_fallback++; c->n_qr_house++;
+    hipError_t e2 = qrpos(m, n, (const double*)A2, lda2, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws, c->stream, &err);
+    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (2) failed");
+  }
+  return MPSK_OK;
 }
 
 // LQ of A (m x n, m <= n) through the QR of A^T:  A^T = Qt Rt  ->  L = Rt^T, Q = Qt^T

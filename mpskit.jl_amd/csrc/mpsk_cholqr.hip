@@ -337,37 +337,61 @@ static hipError_t cq_pass_firstorder(int m, int n, int npad, const double* X, in
   return gemm_f64(g, s);
 }
 
-// Shifted CholeskyQR3.  *flag_out != 0 (host, after a stream sync) means "not trustworthy, fall back".
-hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
-                   int* d_flag, int* flag_out, hipStream_t s) {
+// Shifted CholeskyQR3, split in two halves so that two factorizations can be in flight on two streams:
+//   cholqr3_enqueue  : launches everything (passes 1, 2, first-order pass 3, R product, flag copy) -- no sync
+//   cholqr3_finalize : syncs the stream, repeats pass 3 with the full Cholesky if the device asked for it.
+// *flag_out != 0 after finalize means "not trustworthy, fall back to Householder".
+struct CqBufs { double *R1, *R2, *R3, *Rinv, *T, *Qa, *Qb; int npad; };
+static CqBufs cq_bufs(int m, int n, double* ws) {
   int nb = (n + CB - 1) / CB, p2 = 1;
   while (p2 < nb) p2 <<= 1;
-  const int npad = p2 * CB;
-  const size_t np2 = (size_t)npad * npad;
-  double* R1 = ws; double* R2 = R1 + np2; double* R3 = R2 + np2;
-  double* Rinv = R3 + np2; double* T = Rinv + np2;
-  double* Qa = T + np2; double* Qb = Qa + (size_t)m * n;
+  CqBufs b;
+  b.npad = p2 * CB;
+  const size_t np2 = (size_t)b.npad * b.npad;
+  b.R1 = ws; b.R2 = b.R1 + np2; b.R3 = b.R2 + np2; b.Rinv = b.R3 + np2; b.T = b.Rinv + np2;
+  b.Qa = b.T + np2; b.Qb = b.Qa + (size_t)m * n;
+  return b;
+}
+static hipError_t cq_finish(const CqBufs& b, int n, double* R, int ldr, int* d_flag, int* flag_out, hipStream_t s) {
   hipError_t e;
-  auto finish = [&]() -> hipError_t {   // R = R3 R2 R1 ; flag to host
-    GemmArgs g = cq_mk(R2, R1, T, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
-    if ((e = gemm_f64(g, s)) != hipSuccess) return e;
-    g = cq_mk(R3, T, Rinv, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
-    if ((e = gemm_f64(g, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(cq_copy_upper_kernel, dim3(1024), dim3(256), 0, s, Rinv, npad, n, R, ldr);
-    if ((e = hipMemcpyAsync(flag_out, d_flag, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    return hipStreamSynchronize(s);
-  };
+  GemmArgs g = cq_mk(b.R2, b.R1, b.T, b.npad, b.npad, b.npad, b.npad, b.npad, b.npad, 0, 1.0, 0.0);
+  if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+  g = cq_mk(b.R3, b.T, b.Rinv, b.npad, b.npad, b.npad, b.npad, b.npad, b.npad, 0, 1.0, 0.0);
+  if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(cq_copy_upper_kernel, dim3(1024), dim3(256), 0, s, b.Rinv, b.npad, n, R, ldr);
+  return hipMemcpyAsync(flag_out, d_flag, sizeof(int), hipMemcpyDeviceToHost, s);
+}
+
+hipError_t cholqr3_enqueue(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
+                           int* d_flag, int* flag_out, hipStream_t s) {
+  const CqBufs b = cq_bufs(m, n, ws);
+  hipError_t e;
   if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
-  if ((e = cq_pass(m, n, npad, A, lda, Qa, m, R1, Rinv, T, true, false, d_flag, s)) != hipSuccess) return e;
-  if ((e = cq_pass(m, n, npad, Qa, m, Qb, m, R2, Rinv, T, false, false, d_flag, s)) != hipSuccess) return e;
-  if ((e = cq_pass_firstorder(m, n, npad, Qb, m, Q, ldq, R3, Rinv, T, d_flag, s)) != hipSuccess) return e;
-  if ((e = finish()) != hipSuccess) return e;
+  if ((e = cq_pass(m, n, b.npad, A, lda, b.Qa, m, b.R1, b.Rinv, b.T, true, false, d_flag, s)) != hipSuccess) return e;
+  if ((e = cq_pass(m, n, b.npad, b.Qa, m, b.Qb, m, b.R2, b.Rinv, b.T, false, false, d_flag, s)) != hipSuccess) return e;
+  if ((e = cq_pass_firstorder(m, n, b.npad, b.Qb, m, Q, ldq, b.R3, b.Rinv, b.T, d_flag, s)) != hipSuccess) return e;
+  return cq_finish(b, n, R, ldr, d_flag, flag_out, s);
+}
+
+hipError_t cholqr3_finalize(int m, int n, double* Q, int ldq, double* R, int ldr, double* ws, int* d_flag,
+                            int* flag_out, hipStream_t s) {
+  const CqBufs b = cq_bufs(m, n, ws);
+  hipError_t e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
   if (*flag_out == 4) {                 // Q2 not yet orthogonal to 1e-7: full third pass
     if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
-    if ((e = cq_pass(m, n, npad, Qb, m, Q, ldq, R3, Rinv, T, false, true, d_flag, s)) != hipSuccess) return e;
-    if ((e = finish()) != hipSuccess) return e;
+    if ((e = cq_pass(m, n, b.npad, b.Qb, m, Q, ldq, b.R3, b.Rinv, b.T, false, true, d_flag, s)) != hipSuccess) return e;
+    if ((e = cq_finish(b, n, R, ldr, d_flag, flag_out, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
   }
   return hipGetLastError();
+}
+
+hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
+                   int* d_flag, int* flag_out, hipStream_t s) {
+  hipError_t e = cholqr3_enqueue(m, n, A, lda, Q, ldq, R, ldr, ws, d_flag, flag_out, s);
+  if (e != hipSuccess) return e;
+  return cholqr3_finalize(m, n, Q, ldq, R, ldr, ws, d_flag, flag_out, s);
 }
 
 }  // namespace mpsk

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -86,8 +87,12 @@ template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
   }
 };
 
+// Accumulate the flattened k-tile range [ktb, kte) (k-tile t = segment t / tps, offset (t % tps) * BK)
+// of the output tile at (m0, n0) into the MFMA accumulators.  Ends with a barrier: LDS is reusable.
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g) {
+__device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double* __restrict__ Ab,
+                                                const double* __restrict__ Bb, int m0, int n0, int ktb, int kte,
+                                                d4 (&acc)[BM / 32][BN / 32], double* smem) {
   constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile (2x2 waves)
   constexpr int TM = WTM / 16, TN = WTN / 16; // MFMA tiles per wave
   // A is "k-contiguous" when transposed, B is "k-contiguous" when NOT transposed
@@ -95,54 +100,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   using LB = TileLoader<BN, !TB, ALIGNED>;
   using IA = typename LA::Img;
   using IB = typename LB::Img;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const sA = smem;                  // two A images, then two B images
   double* const sB = smem + 2 * IA::SIZE;
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int fr = lane & 15, fq = lane >> 4;
-
-  // XCD-aware tile mapping: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
-  // chunk of the tile list so neighbouring tiles (sharing an A row panel) hit the same L2.
-  const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-  const int ntiles = tilesM * tilesN;
-  int bid = blockIdx.x;
-  {
-    int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, pos = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  }
-  const int bm = bid % tilesM, bn = bid / tilesM;
-  const int z = blockIdx.y;
-  const int m0 = bm * BM, n0 = bn * BN;
-
-  const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
-  const double* Bb = g.B + (g.tabB ? g.tabB[z] : (int64_t)z * g.bsB);
-  double* Cb = g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC);
-
-  d4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-
   const int tps = (g.K + BK - 1) / BK;  // k-tiles per segment
-  const int nt = tps * g.nseg;
   LA la; LB lb;
-
-  la.load(Ab + g.segA[0], g.lda, m0, 0, g.M, g.K, tid);
-  lb.load(Bb + g.segB[0], g.ldb, n0, 0, g.N, g.K, tid);
+  int seg = ktb / tps, kt = ktb % tps;
+  la.load(Ab + g.segA[seg], g.lda, m0, kt * BK, g.M, g.K, tid);
+  lb.load(Bb + g.segB[seg], g.ldb, n0, kt * BK, g.N, g.K, tid);
   la.store(sA, tid);
   lb.store(sB, tid);
   __syncthreads();
-
-  int seg = 0, kt = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
+  for (int t = ktb; t < kte; ++t) {
+    const int cur = (t - ktb) & 1;
     int kt2 = kt + 1, seg2 = seg;
     if (kt2 == tps) { kt2 = 0; seg2 = seg + 1; }
-    if (t + 1 < nt) {
+    if (t + 1 < kte) {
       la.load(Ab + g.segA[seg2], g.lda, m0, kt2 * BK, g.M, g.K, tid);
       lb.load(Bb + g.segB[seg2], g.ldb, n0, kt2 * BK, g.N, g.K, tid);
     }
@@ -161,15 +137,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nt) {
+    if (t + 1 < kte) {
       la.store(sA + (cur ^ 1) * IA::SIZE, tid);
       lb.store(sB + (cur ^ 1) * IB::SIZE, tid);
     }
     __syncthreads();
     kt = kt2; seg = seg2;
   }
+}
 
-  // epilogue: lane holds C[m = .. + fr][n = .. + fq + 4*reg]
+// epilogue: lane holds C[m = .. + fr][n = .. + fq + 4*reg]
+template <int BM, int BN, bool ALIGNED>
+__device__ __forceinline__ void gemm_store_c(const GemmArgs& g, double* __restrict__ Cb, int z, int m0, int n0,
+                                             const d4 (&acc)[BM / 32][BN / 32]) {
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1, fr = lane & 15, fq = lane >> 4;
   const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -192,6 +175,155 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   }
 }
 
+// partial tile -> dense BM x BN workspace slot (stream-K parts that do not start at k = 0)
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_store_ws(double alpha, double* __restrict__ slot, const d4 (&acc)[BM / 32][BN / 32]) {
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1, fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        slot[(wm * WTM + i * 16 + fr) + (wn * WTN + j * 16 + fq + 4 * rg) * BM] = alpha * acc[i][j][rg];
+}
+
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // XCD-aware tile mapping: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
+  // chunk of the tile list so neighbouring tiles (sharing an A row panel) hit the same L2.
+  const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+  const int ntiles = tilesM * tilesN;
+  int bid = blockIdx.x;
+  {
+    int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, pos = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int bm = bid % tilesM, bn = bid / tilesM;
+  const int z = blockIdx.y;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
+  const double* Bb = g.B + (g.tabB ? g.tabB[z] : (int64_t)z * g.bsB);
+  double* Cb = g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC);
+  d4 acc[BM / 32][BN / 32];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  const int nt = ((g.K + BK - 1) / BK) * g.nseg;
+  gemm_accumulate<BM, BN, TA, TB, ALIGNED>(g, Ab, Bb, m0, n0, 0, nt, acc, smem);
+  gemm_store_c<BM, BN, ALIGNED>(g, Cb, z, m0, n0, acc);
+}
+
+// ---- stream-K: equal shares of the flattened (tile, k-tile) work list ---------------------------
+// Workgroup i owns units [i*g.sk_units, (i+1)*g.sk_units) of the list  unit = (z*ntiles + tile)*KT + kt.
+// A share that starts at kt == 0 of a tile writes C (with alpha / beta); a share that starts in the
+// middle of a tile writes its partial tile to workspace slot i, and gemm_sk_fixup_kernel adds the
+// slots to C in a fixed order (deterministic, no atomics).  This removes the wave-quantisation loss
+// of big tiles (640 tiles of 128x128 on 512 resident workgroups at the north-star point).
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+__device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+  const int ntiles = tilesM * tilesN;
+  const int KT = ((g.K + BK - 1) / BK) * g.nseg;
+  const int U = ntiles * g.batch * KT;
+  // XCD-aware share order: workgroups b, b+8, ... share an L2 -> give each XCD a contiguous run of shares
+  int sid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    int q = nwg / 8, r = nwg % 8, xcd = sid % 8, pos = sid / 8;
+    sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  int u = sid * g.sk_units;
+  const int uend = (u + g.sk_units < U) ? u + g.sk_units : U;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1, fr = lane & 15, fq = lane >> 4;
+  while (u < uend) {
+    const int tz = u / KT;
+    const int kt0 = u - tz * KT;
+    const int kt1 = (uend - u < KT - kt0) ? kt0 + (uend - u) : KT;
+    const int z = tz / ntiles, tile = tz - z * ntiles;
+    const int bn = tile / tilesM, bm = tile - bn * tilesM;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
+    const double* Bb = g.B + (g.tabB ? g.tabB[z] : (int64_t)z * g.bsB);
+    d4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    gemm_accumulate<BM, BN, TA, TB, ALIGNED>(g, Ab, Bb, m0, n0, kt0, kt1, acc, smem);
+    // one epilogue for both destinations (uniform parameters): C tile (kt0 == 0) or workspace slot
+    const bool toC = (kt0 == 0);
+    double* base = toC ? g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC) + m0 + (int64_t)n0 * g.ldc
+                       : g.sk_ws + (int64_t)sid * BM * BN;
+    const int64_t ld = toC ? g.ldc : BM;
+    const double beta = toC ? g.beta : 0.0;
+    const double alpha = g.alpha;
+    const int mlim = toC ? g.M - m0 : BM, nlim = toC ? g.N - n0 : BN;
+    const bool split = toC && g.tabC2 != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = wm * WTM + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int n = wn * WTN + j * 16 + fq + 4 * rg;
+          if (m < mlim && n < nlim) {
+            double* p = base + m + (int64_t)n * ld;
+            if (split && n0 + n >= g.splitN) p = g.C + g.tabC2[z] + (m0 + m) + (int64_t)(n0 + n - g.splitN) * g.ldc;
+            double v = alpha * acc[i][j][rg];
+            if (beta != 0.0) v += beta * (*p);
+            *p = v;
+          }
+        }
+      }
+    }
+    u += kt1 - kt0;
+  }
+}
+
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_sk_f64_kernel(GemmArgs g) {
+  gemm_sk_body<BM, BN, TA, TB, ALIGNED>(g);
+}
+template <int BM, int BN, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_sk_f64_kernel(GemmArgs g) {
+  gemm_sk_body<BM, BN, false, false, ALIGNED>(g);
+}
+
+// C tile += sum of the workspace slots of the shares that start strictly inside this tile's k-range
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs g) {
+  const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+  const int ntiles = tilesM * tilesN;
+  const int KT = ((g.K + BK - 1) / BK) * g.nseg;
+  const int tz = blockIdx.x;
+  const int z = tz / ntiles, tile = tz % ntiles;
+  const int u0 = tz * KT, u1 = u0 + KT;
+  const int i = u0 / g.sk_units + 1;           // first (logical) share that can start inside (u0, u1)
+  if (i * g.sk_units >= u1) return;            // tile not split
+  const int bm = tile % tilesM, bn = tile / tilesM;
+  const int m0 = bm * BM, n0 = bn * BN;
+  double* Cb = g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC);
+  for (int e = threadIdx.x; e < BM * BN; e += 256) {
+    const int m = e % BM, n = e / BM;
+    if (m0 + m >= g.M || n0 + n >= g.N) continue;
+    double s = 0.0;
+    for (int w = i; w * g.sk_units < u1; ++w) s += g.sk_ws[(int64_t)w * BM * BN + e];
+    const int gn = n0 + n;
+    double* p = (g.tabC2 != nullptr && gn >= g.splitN) ? g.C + g.tabC2[z] + (m0 + m) + (int64_t)(gn - g.splitN) * g.ldc
+                                                       : Cb + (m0 + m) + (int64_t)gn * g.ldc;
+    *p += s;
+  }
+}
+
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
   gemm_body<BM, BN, TA, TB, ALIGNED>(g);
@@ -206,7 +338,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_f64_kernel(GemmArgs g) {
 }
 
 // ---- event profile of the tagged (matvec) launches ---------------------------------------------
-struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned, sk; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
@@ -227,7 +359,8 @@ std::string gemm_prof_summary() {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     char key[96];
-    snprintf(key, sizeof(key), "dac_gemm_f64_kernel<%d,%d,%s>", r.bm, r.bn, r.aligned ? "true" : "false");
+    snprintf(key, sizeof(key), "%s<%d,%d,%s>", r.sk ? "dac_gemm_sk_f64_kernel" : "dac_gemm_f64_kernel", r.bm, r.bn,
+             r.aligned ? "true" : "false");
     Agg& a = agg[key];
     a.n++; a.ms += ms; a.flops += r.flops;
   }
@@ -259,6 +392,38 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   }
   const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
   dim3 grid(tilesM * tilesN, g.batch, 1);
+  if constexpr ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) {
+    if (g.sk_units > 0) {   // stream-K launch: equal k-tile shares + fixed-order fixup of split tiles
+      const int KT = ((g.K + BK - 1) / BK) * g.nseg;
+      const int64_t U = (int64_t)tilesM * tilesN * g.batch * KT;
+      const int nwg = (int)((U + g.sk_units - 1) / g.sk_units);
+      const void* kp = (g.tag == 1 && !TA && !TB) ? reinterpret_cast<const void*>(dac_gemm_sk_f64_kernel<BM, BN, ALIGNED>)
+                                                   : reinterpret_cast<const void*>(gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>);
+      static bool sattr[2] = {false, false};
+      const int which = (g.tag == 1 && !TA && !TB) ? 1 : 0;
+      if (!sattr[which]) {
+        hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        sattr[which] = true;
+      }
+      ProfRec r;
+      const bool prof = g_prof_on && which == 1;
+      if (prof) {
+        r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 1;
+        (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, s);
+      }
+      if (which == 1) {
+        if constexpr (!TA && !TB)
+          hipLaunchKernelGGL((dac_gemm_sk_f64_kernel<BM, BN, ALIGNED>), dim3(nwg), dim3(NTHREADS), smem, s, g);
+      } else {
+        hipLaunchKernelGGL((gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>), dim3(nwg), dim3(NTHREADS), smem, s, g);
+      }
+      if (prof) { (void)hipEventRecord(r.e1, s); g_prof.push_back(r); }
+      hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN>), dim3(tilesM * tilesN * g.batch), dim3(256), 0, s, g);
+      return hipGetLastError();
+    }
+  }
   if constexpr (!TA && !TB) {
     if (g.tag == 1) {
       auto dk = dac_gemm_f64_kernel<BM, BN, ALIGNED>;
@@ -271,7 +436,7 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
       }
       if (g_prof_on) {
         ProfRec r;
-        r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED;
+        r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 0;
         (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
         (void)hipEventRecord(r.e0, s);
         hipLaunchKernelGGL(dk, grid, dim3(NTHREADS), smem, s, g);
@@ -308,6 +473,20 @@ static void choose_tile(int M, int N, int batch, int* bm, int* bn) {
 
 static int g_force_bm = 0, g_force_bn = 0;
 void gemm_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
+// Stream-K is implemented and parity-tested but OFF by default: on MI355X it measured no gain over
+// the data-parallel 64x64 tiling (D = 1024: 47.5 vs 47.8-50.4 TF/s, tools/bench_dac.py A/B) -- the
+// 128x128 stream-K body sits at the 256-VGPR cap and the fixup pass eats the balance it buys.
+// MPSK_STREAMK=1 enables it (single-stream use only: the partial-tile workspace is per device).
+static bool g_sk_enabled = (getenv("MPSK_STREAMK") != nullptr) && (getenv("MPSK_STREAMK")[0] == '1');
+void gemm_enable_streamk(bool on) { g_sk_enabled = on; }
+constexpr size_t SK_WS_DOUBLES = (size_t)1024 * 128 * 128 / 2;   // 512 slots of 128x128 == 2048 slots of 64x64
+static double* sk_workspace() {       // per-device, allocated once, never freed (64 MiB)
+  static double* ws[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!ws[dev]) { if (hipMalloc(&ws[dev], SK_WS_DOUBLES * sizeof(double)) != hipSuccess) ws[dev] = nullptr; }
+  return ws[dev];
+}
 
 hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   GemmArgs g = g_in;
@@ -317,7 +496,30 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   }
   int bm = 128, bn = 128;
   choose_tile(g.M, g.N, g.batch, &bm, &bn);
+  g.sk_units = 0;
+  g.sk_ws = nullptr;
   if (g_force_bm) { bm = g_force_bm; bn = g_force_bn; }
+  else if (g_sk_enabled) {
+    // stream-K decision (see gemm_sk_body): big tiles when they would otherwise leave a ragged last
+    // wave (T not a multiple of the 512 resident workgroups and fewer than 4 waves), small tiles
+    // with split K when there are too few tiles to fill the chip.
+    const int KT = ((g.K + BK - 1) / BK) * g.nseg;
+    const int64_t Tb = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    const int64_t Ts = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch;
+    double* ws = sk_workspace();
+    if (ws != nullptr) {
+      const int64_t Ub = Tb * KT, Us = Ts * KT;
+      if (Tb >= 128 && Tb < 4 * 512 && Tb % 512 != 0 && Ub / 512 >= 16) {
+        bm = bn = 128; g.sk_units = (int)((Ub + 511) / 512); g.sk_ws = ws;
+      } else if (Tb < 128 && Ts < 1024 && Us >= 64) {
+        int64_t nwg = Us / 8;                       // >= 8 k-tiles per workgroup
+        if (nwg > 1024) nwg = 1024;
+        if (nwg < 1) nwg = 1;
+        bm = bn = 64; g.sk_units = (int)((Us + nwg - 1) / nwg); g.sk_ws = ws;
+        if (g.sk_units >= KT && Ts >= nwg) { g.sk_units = 0; g.sk_ws = nullptr; }   // whole tiles anyway
+      }
+    }
+  }
   bool aligned = (g.M % bm == 0) && (g.N % bn == 0) && (g.K % BK == 0) && (g.lda % 2 == 0) &&
                  (g.ldb % 2 == 0) && (g.bsA % 2 == 0) && (g.bsB % 2 == 0) &&
                  ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);

@@ -29,12 +29,16 @@ struct GemmArgs {
   // optional column split of C: columns n >= splitN of batch z go to C + tabC2[z] + (n - splitN)*ldc
   const int64_t* tabC2;
   int splitN;
+  // stream-K (set by gemm_f64 itself): units of k-tiles per workgroup and the partial-tile workspace
+  int sk_units;
+  double* sk_ws;
   int tag;                   // 1: matvec-stage launch (own kernel symbol + event profile)
   int tabs_even;             // caller guarantees every tabA/tabB entry is even (16-B aligned operands)
 };
 
 hipError_t gemm_f64(const GemmArgs& g, hipStream_t s);
 void gemm_force_tile(int bm, int bn);
+void gemm_enable_streamk(bool on);
 void gemm_prof_enable(bool on);
 std::string gemm_prof_summary();
 
@@ -83,6 +87,10 @@ hipError_t qrpos(int m, int n, const double* A, int lda, double* Q, int ldq, dou
 size_t cholqr_workspace_doubles(int m, int n);
 hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                    int* d_flag, int* flag_out, hipStream_t s);
+hipError_t cholqr3_enqueue(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
+                           int* d_flag, int* flag_out, hipStream_t s);
+hipError_t cholqr3_finalize(int m, int n, double* Q, int ldq, double* R, int ldr, double* ws, int* d_flag,
+                            int* flag_out, hipStream_t s);
 size_t tsvd_workspace_bytes(int m, int n);
 hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
                 int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,

@@ -141,6 +141,30 @@ class FiniteMPS:
         else:
             self.ACs[i] = vec
 
+    def set_AC_with_leftorth(self, i, vec):
+        """Right-moving site update: the reference computes leftorth(old AC[i]) for calc_galerkin
+        (toolbox.jl:20, via AL[i] -> CRView, orthoview.jl:56) and leftorth(new AC[i]) when AL[i] is next
+        needed (FinEnv.jl:136).  Both inputs are known once the eigensolver returns, so the two QRpos
+        factorizations are issued TOGETHER (mpsk_qrpos2) and the state is left exactly as the lazy views
+        would leave it.  Returns the OLD AL[i] (the galerkin projector)."""
+        be = self.be
+        if self.ALs[i] is not None or self.ACs[i] is None or not hasattr(be, "qrpos2"):
+            al_old = self.AL(i)
+            self.set_AC(i, vec)
+            return al_old
+        old = self.ACs[i]
+        Dl, d, Dr = old.shape
+        if vec.shape != old.shape or Dl * d < Dr:
+            al_old = self.AL(i)
+            self.set_AC(i, vec)
+            return al_old
+        Q1, R1, Q2, R2 = be.qrpos2(old.reshape(Dl * d, Dr), vec.reshape(Dl * d, Dr))
+        al_old = Q1.reshape(Dl, d, Dr)
+        self.ALs[i], self.CLs[i + 1] = al_old, R1          # what CR(i) would have cached
+        self.set_AC(i, vec)                                 # invalidates, stores ACs[i] = vec
+        self.ALs[i], self.CLs[i + 1] = Q2.reshape(Dl, d, Dr), R2   # what the next AL(i) / CR(i) computes
+        return al_old
+
     def norm(self):  # finitemps.jl:467
         return self.be.norm(self.AC(0))
 

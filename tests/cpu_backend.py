@@ -175,6 +175,12 @@ class CpuBackend:
         q, r = mo.qrpos(self.download(A))
         return self.upload(q), self.upload(r)
 
+    def qrpos2(self, A1, A2):
+        self._count("qrpos2")
+        q1, r1 = self.qrpos(A1)
+        q2, r2 = self.qrpos(A2)
+        return q1, r1, q2, r2
+
     def lqpos(self, A):
         self._count("lqpos")
         l, q = mo.lqpos(self.download(A))
