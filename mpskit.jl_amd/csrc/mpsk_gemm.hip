@@ -479,13 +479,21 @@ void gemm_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 // MPSK_STREAMK=1 enables it (single-stream use only: the partial-tile workspace is per device).
 static bool g_sk_enabled = (getenv("MPSK_STREAMK") != nullptr) && (getenv("MPSK_STREAMK")[0] == '1');
 void gemm_enable_streamk(bool on) { g_sk_enabled = on; }
+static bool g_splitk_enabled = (getenv("MPSK_SPLITK") == nullptr) || (getenv("MPSK_SPLITK")[0] != '0');
 constexpr size_t SK_WS_DOUBLES = (size_t)1024 * 128 * 128 / 2;   // 512 slots of 128x128 == 2048 slots of 64x64
-static double* sk_workspace() {       // per-device, allocated once, never freed (64 MiB)
-  static double* ws[16] = {nullptr};
+// partial-tile workspace: one per (device, stream) so that concurrent streams never share slots;
+// allocated on first use, never freed (64 MiB each)
+static double* sk_workspace(hipStream_t s) {
+  static std::map<std::pair<int, hipStream_t>, double*> ws;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!ws[dev]) { if (hipMalloc(&ws[dev], SK_WS_DOUBLES * sizeof(double)) != hipSuccess) ws[dev] = nullptr; }
-  return ws[dev];
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto key = std::make_pair(dev, s);
+  auto it = ws.find(key);
+  if (it != ws.end()) return it->second;
+  double* p = nullptr;
+  if (hipMalloc(&p, SK_WS_DOUBLES * sizeof(double)) != hipSuccess) p = nullptr;
+  ws[key] = p;
+  return p;
 }
 
 hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
@@ -499,24 +507,28 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   g.sk_units = 0;
   g.sk_ws = nullptr;
   if (g_force_bm) { bm = g_force_bm; bn = g_force_bn; }
-  else if (g_sk_enabled) {
-    // stream-K decision (see gemm_sk_body): big tiles when they would otherwise leave a ragged last
-    // wave (T not a multiple of the 512 resident workgroups and fewer than 4 waves), small tiles
-    // with split K when there are too few tiles to fill the chip.
+  else {
     const int KT = ((g.K + BK - 1) / BK) * g.nseg;
     const int64_t Tb = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
     const int64_t Ts = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch;
-    double* ws = sk_workspace();
-    if (ws != nullptr) {
-      const int64_t Ub = Tb * KT, Us = Ts * KT;
+    if (g_sk_enabled) {
+      // full stream-K (experimental, MPSK_STREAMK=1): big tiles with equal k-tile shares
+      const int64_t Ub = Tb * KT;
       if (Tb >= 128 && Tb < 4 * 512 && Tb % 512 != 0 && Ub / 512 >= 16) {
-        bm = bn = 128; g.sk_units = (int)((Ub + 511) / 512); g.sk_ws = ws;
-      } else if (Tb < 128 && Ts < 1024 && Us >= 64) {
-        int64_t nwg = Us / 8;                       // >= 8 k-tiles per workgroup
-        if (nwg > 1024) nwg = 1024;
-        if (nwg < 1) nwg = 1;
-        bm = bn = 64; g.sk_units = (int)((Us + nwg - 1) / nwg); g.sk_ws = ws;
-        if (g.sk_units >= KT && Ts >= nwg) { g.sk_units = 0; g.sk_ws = nullptr; }   // whole tiles anyway
+        double* ws = sk_workspace(s);
+        if (ws) { bm = bn = 128; g.sk_units = (int)((Ub + 511) / 512); g.sk_ws = ws; }
+      }
+    }
+    if (g.sk_units == 0 && g_splitk_enabled && bm == 64 && bn == 64 && Ts <= 512 && KT >= 32) {
+      // split-K for long-K GEMMs with too few 64x64 tiles to fill the chip (<= 2 workgroups per CU):
+      // f shares per tile through the stream-K body (first share writes C, the others a workspace
+      // slot, fixed-order fixup).  E.g. stage 3 of dAC at D = 1024: 512 tiles x 320 k-tiles -> f = 2.
+      int f = (int)(1024 / Ts);
+      if (f > 8) f = 8;
+      while (f > 1 && KT / f < 16) --f;
+      if (f >= 2) {
+        double* ws = sk_workspace(s);
+        if (ws) { g.sk_units = (KT + f - 1) / f; g.sk_ws = ws; }
       }
     }
   }

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -25,6 +27,14 @@ namespace mpsk {
 
 constexpr int JB = 32;
 constexpr int J2 = 64;
+
+typedef double sv_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double sv_readlane(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
 
 __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restrict__ Mpart, int Q,
                                                          double* __restrict__ Wout, double tol,
@@ -38,11 +48,22 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
   const int tid = threadIdx.x;
   const int p = blockIdx.x;
   const double* Mp = Mpart + (size_t)p * Q * J2 * J2;
-  for (int e = tid; e < J2 * J2; e += 256) {
-    double s = 0.0;
-    for (int q = 0; q < Q; ++q) s += Mp[(size_t)q * J2 * J2 + e];
-    Ms[e % J2][e / J2] = s;          // Ms[i][j], column-major source
-    Ws[e % J2][e / J2] = (e % J2 == e / J2) ? 1.0 : 0.0;
+  {
+    double accv[16];                   // 16 independent running sums per thread: loads stay in flight
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accv[i] = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < Q; ++q) {
+      const double* mq = Mp + (size_t)q * J2 * J2 + tid;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accv[i] += mq[256 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i;
+      Ms[e % J2][e / J2] = accv[i];    // Ms[i][j], column-major source
+      Ws[e % J2][e / J2] = (e % J2 == e / J2) ? 1.0 : 0.0;
+    }
   }
   __syncthreads();
   // symmetrise + convergence measure of this pair
@@ -78,70 +99,138 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
   }
   __syncthreads();
 
-  // Two inner sweeps per visit are enough: the outer block-Jacobi iteration converges anyway and
-  // its rotations become tiny (quadratic convergence); a full inner diagonalisation (6-8 sweeps of
-  // 63 latency-bound steps) made this kernel ~2 ms per round (profiles/r01_other_configs.log).
-  // Thread (k = tid >> 3, j = tid & 7) owns pair k and rows/columns j + 8 i: all LDS reads of a phase
-  // are issued before the arithmetic (one latency, not eight).
+  // ---- inner solve: M = R^T R (Cholesky on the matrix cores, semi-definite safe), then ONE-SIDED
+  // Jacobi on the columns of R (R W has orthogonal columns  <=>  W^T M W diagonal).  One barrier per
+  // step and no serial parameter phase: every pair (p, q) of a step is owned by 8 lanes that form the
+  // three dot products with two shuffles and rotate their 8 rows of R and W.  (The earlier two-sided
+  // LDS version cost ~2.5 us per step = 315 us per call, 85 % of the SVD; profiles/r01_other_configs.)
+  {
+    // (1) Cholesky, rows four at a time, rank-4 MFMA updates (same scheme as cq_potrf64_mfma_kernel)
+    __shared__ double P[2][4][J2];
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane >> 4, lc = lane & 15;
+    // symmetric scaling to unit diagonal: the column norms of X can span many orders of magnitude
+    // (graded singular values); chol(D^-1 M D^-1) is then well behaved and R = R~ D has Gram M.
+    __shared__ double dsc[J2], dinv[J2];
+    if (tid < J2) {
+      const double dd = Ms[tid][tid];
+      dsc[tid] = dd > 0.0 ? sqrt(dd) : 0.0;
+      dinv[tid] = dd > 0.0 ? 1.0 / sqrt(dd) : 0.0;
+    }
+    __syncthreads();
+    sv_d4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int rr = 32 * wr + 16 * ti + lr + 4 * rg, cc = 32 * wc + 16 * tj + lc;
+          acc[ti][tj][rg] = (rr == cc) ? (dinv[rr] > 0.0 ? 1.0 : 0.0) : Ms[rr][cc] * dinv[rr] * dinv[cc];
+        }
+    const double ptol = 1.0e-14;
+    __syncthreads();                       // everyone has read Ms before it is overwritten with R
+    for (int c = 0; c < J2 / 4; ++c) {
+      const int j0 = 4 * c;
+      double (*Pb)[J2] = P[c & 1];
+      if (wr == (j0 >> 5)) {
+        const int ti = (j0 >> 4) & 1, q = (j0 >> 2) & 3;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          const sv_d4 v = ti ? acc[1][tj] : acc[0][tj];
+          Pb[lr][32 * wc + 16 * tj + lc] = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        double pr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pr[t] = Pb[t][lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double piv = sv_readlane(pr[t], j0 + t);
+          const bool ok = (piv > ptol) && (piv < 1.0e300);     // semi-definite: a vanishing pivot zeroes the row
+          const double sq = ok ? sqrt(piv) : 0.0;
+          const double rs = ok ? 1.0 / sq : 0.0;
+          pr[t] = (lane > j0 + t) ? pr[t] * rs : (lane == j0 + t ? sq : 0.0);
+#pragma unroll
+          for (int u = t + 1; u < 4; ++u) pr[u] -= sv_readlane(pr[t], j0 + u) * pr[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { Pb[t][lane] = pr[t]; Ms[j0 + t][lane] = pr[t] * dsc[lane]; }   // row j0+t of R = R~ D
+      }
+      __syncthreads();
+      double af[2], bf[2];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) af[ti] = -Pb[lr][32 * wr + 16 * ti + lc];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) bf[tj] = Pb[lr][32 * wc + 16 * tj + lc];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // (2) one-sided Jacobi on R = Ms (upper triangular), W = Ws
   const int pk = tid >> 3, pj = tid & 7;
-  for (int sweep = 0; sweep < 2; ++sweep) {
+  for (int sweep = 0; sweep < 3; ++sweep) {
     if (tid == 0) any_rot = 0;
     __syncthreads();
+    int rotated = 0;
     for (int st = 0; st < J2 - 1; ++st) {
-      if (tid < J2 / 2) {
-        int pp, qq;
-        if (tid == 0) { pp = J2 - 1; qq = st; }
-        else { pp = (st + tid) % (J2 - 1); qq = (st + (J2 - 1) - tid) % (J2 - 1); }
-        if (pp > qq) { int t = pp; pp = qq; qq = t; }
-        const double app = Ms[pp][pp], aqq = Ms[qq][qq], apq = Ms[pp][qq];
-        double c = 1.0, s = 0.0;
-        if (apq != 0.0 && fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq))) {
-          const double zeta = (aqq - app) / (2.0 * apq);
-          const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          c = 1.0 / sqrt(1.0 + t * t);
-          s = c * t;
-          if (fabs(apq) > 2.3e-16 * sqrt(fabs(app * aqq))) any_rot = 1;
-        }
-        cs_c[tid] = c; cs_s[tid] = s; cs_p[tid] = pp; cs_q[tid] = qq;
+      int pp, qq;
+      if (pk == 0) { pp = J2 - 1; qq = st; }
+      else { pp = (st + pk) % (J2 - 1); qq = (st + (J2 - 1) - pk) % (J2 - 1); }
+      if (pp > qq) { const int t = pp; pp = qq; qq = t; }
+      double rp[8], rq[8], wp[8], wq[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = pj + 8 * i;
+        rp[i] = Ms[r][pp]; rq[i] = Ms[r][qq]; wp[i] = Ws[r][pp]; wq[i] = Ws[r][qq];
       }
-      __syncthreads();
-      const double c = cs_c[pk], sn = cs_s[pk];
-      const int pp = cs_p[pk], qq = cs_q[pk];
-      {   // columns:  M <- M J,  W <- W J
-        double mp[8], mq[8], wp[8], wq[8];
+      double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = pj + 8 * i;
-          mp[i] = Ms[r][pp]; mq[i] = Ms[r][qq]; wp[i] = Ws[r][pp]; wq[i] = Ws[r][qq];
-        }
+      for (int i = 0; i < 8; ++i) { al += rp[i] * rp[i]; be += rq[i] * rq[i]; ga += rp[i] * rq[i]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = pj + 8 * i;
-          Ms[r][pp] = c * mp[i] - sn * mq[i];
-          Ms[r][qq] = sn * mp[i] + c * mq[i];
-          Ws[r][pp] = c * wp[i] - sn * wq[i];
-          Ws[r][qq] = sn * wp[i] + c * wq[i];
-        }
+      for (int off = 1; off < 8; off <<= 1) {
+        al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
       }
-      __syncthreads();
-      {   // rows:  M <- J^T M ; the rotated off-diagonal entry is set to exactly zero
-        double mp[8], mq[8];
+      // Rotation parameters without fp64 division / square root (each is a ~30-instruction
+      // software sequence and 6 of them per step dominated this kernel): the ANGLE only has to be
+      // approximately right for Jacobi to converge, so t = tan(theta) comes from fp32 hardware
+      // rcp / sqrt; (c, s) must be orthogonal to fp64 accuracy, so c = (1 + t^2)^(-1/2) is an fp32
+      // rsqrt seed polished by two fp64 Newton steps (error ~1e-7 -> 1e-14 -> 1e-28).
+      double c = 1.0, sn = 0.0;
+      const double ab = al * be, gg = ga * ga;
+      if (gg > 1.0e-34 * ab) {
+        const double num = (be - al) * 0.5;
+        int ex;
+        (void)frexp(fmax(fabs(num), fabs(ga)), &ex);       // common power-of-two scale: no fp32 over/underflow
+        const float zf = (float)ldexp(num, -ex) * __frcp_rn((float)ldexp(ga, -ex));
+        const float tf = copysignf(1.0f, zf) * __frcp_rn(fabsf(zf) + __fsqrt_rn(1.0f + zf * zf));
+        const double t = (double)tf;
+        const double x = 1.0 + t * t;
+        double r = (double)__frsqrt_rn((float)x);
+        r = r * (1.5 - 0.5 * x * r * r);
+        r = r * (1.5 - 0.5 * x * r * r);
+        c = r;
+        sn = r * t;
+        if (gg > 5.3e-32 * ab) rotated = 1;
+      }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = pj + 8 * i;
-          mp[i] = Ms[pp][r]; mq[i] = Ms[qq][r];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = pj + 8 * i;
-          double vp = c * mp[i] - sn * mq[i], vq = sn * mp[i] + c * mq[i];
-          if (sn != 0.0) { if (r == qq) vp = 0.0; if (r == pp) vq = 0.0; }
-          Ms[pp][r] = vp;
-          Ms[qq][r] = vq;
-        }
+      for (int i = 0; i < 8; ++i) {
+        const int r = pj + 8 * i;
+        Ms[r][pp] = c * rp[i] - sn * rq[i];
+        Ms[r][qq] = sn * rp[i] + c * rq[i];
+        Ws[r][pp] = c * wp[i] - sn * wq[i];
+        Ws[r][qq] = sn * wp[i] + c * wq[i];
       }
       __syncthreads();
     }
+    if (rotated) any_rot = 1;
+    __syncthreads();
     if (!any_rot) break;
     __syncthreads();
   }
@@ -341,6 +430,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     if (mx <= tol) break;
   }
   if (sweeps_out) *sweeps_out = sweeps;
+  if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] %d x %d: P=%d Q=%d rounds/sweep=%d sweeps=%d\n", mm, nn, P, Q, rounds, sweeps);
 
   // singular values, sorting, truncation (host)
   hipLaunchKernelGGL(colnorm2_kernel, dim3(npad), dim3(256), 0, s, G[cur], mm, mm, sigma2);

@@ -84,6 +84,30 @@ def test_dmrg_matches_oracle_and_ed(be, model, L, D, d):
         assert Eg >= e0 - 1e-9 * abs(e0)
 
 
+def test_dmrg_large_bond_cholqr_path(be):
+    """D = 128 > 64: the gauge steps run through shifted CholeskyQR3 (+ Householder fallback for the
+    numerically rank-deficient tensors of an untruncated chain, Schmidt values down to 1e-16) and the
+    paired two-stream QR; the converged energy still matches the oracle / ED to 1e-10 relative."""
+    mk = _mk()
+    L, D, d = 14, 128, 2
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)
+    rng = np.random.default_rng(77)
+    dims = mo.FiniteMPS.random(L, d, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.random((1 if i == 0 else dims[i - 1], d, dims[i])) for i in range(L)]
+    s0 = be.qr_stats()
+    pg, eg, epsg = mk.find_groundstate(mk.FiniteMPS(As, normalize=True, be=be), Hg, mk.DMRG(tol=1e-10, maxiter=12))
+    s1 = be.qr_stats()
+    assert s1["cholqr3"] > s0["cholqr3"], "CholeskyQR3 path was not exercised"
+    Eg = float(np.sum(mk.expectation_value(pg, Hg, eg)))
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
+    assert epsg < 1e-9
+    assert abs(Eg - e0) <= 1e-10 * abs(e0)
+    # canonical form survived the mixed QR paths
+    for i in (3, 7, 10):
+        al = be.download(pg.AL(i))
+        assert np.abs(np.einsum("asb,asc->bc", al, al) - np.eye(al.shape[2])).max() < 1e-12
+
+
 def test_dmrg_reference_recorded_energy(be):
     """docs/src/examples/quantum1d/3.ising-dqpt/index.md:34-48 : TFI (|g| = 0.5) OBC L = 20 D = 10,
     E = -20.40021786703 after 5 sweeps of the reference's DMRG."""

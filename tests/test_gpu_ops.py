@@ -181,6 +181,22 @@ def test_qrpos_fallback_counts(be):
     assert s1["fallback"] == s0["fallback"] + 1 and s1["householder"] == s0["householder"] + 1
 
 
+@pytest.mark.parametrize("m,n", [(8, 4), (768, 256), (2048, 1024)])
+def test_qrpos2_pair(be, m, n):
+    """two factorizations in flight on two streams == two single calls (incl. one rank-deficient input)."""
+    rng = np.random.default_rng(m + n)
+    A1, A2 = rng.random((m, n)), rng.standard_normal((m, n))
+    if n > 64:
+        A2[:, 3] = 0.0                      # forces the Householder fallback for the second matrix only
+    Q1, R1, Q2, R2 = (be.download(t) for t in be.qrpos2(be.upload(A1), be.upload(A2)))
+    for A, Q, R in ((A1, Q1, R1), (A2, Q2, R2)):
+        assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-12
+        assert relerr(Q @ R, A) < 1e-12
+        assert np.all(np.diag(R) >= 0) and np.abs(np.tril(R, -1)).max(initial=0.0) == 0.0
+    Qs, Rs = (be.download(t) for t in be.qrpos(be.upload(A1)))
+    assert relerr(Q1, Qs) < 1e-12 and relerr(R1, Rs) < 1e-12
+
+
 @pytest.mark.parametrize("m,n", QR_CASES)
 def test_qrpos(be, qr_mode, m, n):
     rng = np.random.default_rng(m * 31 + n)
