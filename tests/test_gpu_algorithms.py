@@ -99,9 +99,9 @@ def test_dmrg_large_bond_cholqr_path(be):
     s1 = be.qr_stats()
     assert s1["cholqr3"] > s0["cholqr3"], "CholeskyQR3 path was not exercised"
     Eg = float(np.sum(mk.expectation_value(pg, Hg, eg)))
-    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
-    assert epsg < 1e-9
-    assert abs(Eg - e0) <= 1e-10 * abs(e0)
+    _, _, epso, logo = mo.dmrg(mo.FiniteMPS(As, normalize=True), Ho, tol=1e-10, maxiter=12)
+    assert epsg < 1e-9 and epso < 1e-9
+    assert abs(Eg - logo[-1][1]) <= 1e-10 * abs(Eg)
     # canonical form survived the mixed QR paths
     for i in (3, 7, 10):
         al = be.download(pg.AL(i))
