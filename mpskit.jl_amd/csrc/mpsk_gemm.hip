@@ -124,18 +124,26 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
     }
     const double* a_s = sA + cur * IA::SIZE;
     const double* b_s = sB + cur * IB::SIZE;
+    // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+    double af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = a_s[IA::idx(wm * WTM + i * 16 + fr, fq)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = b_s[IB::idx(wn * WTN + j * 16 + fr, fq)];
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      double af[TM], bf[TN];
+      const int cb = (ks >> 2) & 1, nb = cb ^ 1;
+      if (ks + 4 < BK) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = a_s[IA::idx(wm * WTM + i * 16 + fr, ks + fq)];
+        for (int i = 0; i < TM; ++i) af[nb][i] = a_s[IA::idx(wm * WTM + i * 16 + fr, ks + 4 + fq)];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = b_s[IB::idx(wn * WTN + j * 16 + fr, ks + fq)];
+        for (int j = 0; j < TN; ++j) bf[nb][j] = b_s[IB::idx(wn * WTN + j * 16 + fr, ks + 4 + fq)];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < kte) {
       la.store(sA + (cur ^ 1) * IA::SIZE, tid);
