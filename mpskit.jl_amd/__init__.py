@@ -9,5 +9,5 @@ from .operators import MPOHamiltonian, heisenberg_XXX, transverse_field_ising, h
 from .states import FiniteMPS, InfiniteMPS  # noqa: F401,E402
 from .environments import FinEnv, MPOHamInfEnv, environments  # noqa: F401,E402
 from .derivatives import ddAC, ddAC2, ddC, MPO_ddAC, MPO_ddAC2, MPO_ddC  # noqa: F401,E402
-from .algorithms import (DMRG, DMRG2, VUMPS, Arnoldi, find_groundstate, calc_galerkin,  # noqa: F401,E402
-                         expectation_value)
+from .algorithms import (DMRG, DMRG2, VUMPS, TDVP, TDVP2, Arnoldi, find_groundstate, calc_galerkin,  # noqa: F401,E402
+                         expectation_value, timestep, time_evolve)

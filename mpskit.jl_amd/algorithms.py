@@ -316,3 +316,121 @@ def _vumps(psi, H, alg: VUMPS, envs=None):  # vumps.jl:29-92
             break
     envs.history = history
     return psi, envs, eps
+
+
+# ---- time evolution (src/algorithms/timestep/tdvp.jl, integrators.jl, time_evolve.jl) ---------------
+
+@dataclass
+class TDVP:  # tdvp.jl:14-19 ; integrator = Lanczos(; tol = Defaults.tol)
+    tol: float = 1e-12
+    krylovdim: int = 30
+    maxiter: int = 100
+    tolgauge: float = 1e-14
+    gaugemaxiter: int = 100
+    finalize: object = None
+
+
+@dataclass
+class TDVP2:  # tdvp.jl:105-111 ; trscheme = truncerr(1e-3)
+    tol: float = 1e-12
+    krylovdim: int = 30
+    maxiter: int = 100
+    trunc_dim: int = 0
+    trunc_err: float = 1e-3
+    finalize: object = None
+
+
+def integrate(be, f, y0, t, dt, alg, ws=None):
+    """integrate(f, y0, t, dt, Lanczos)  (integrators.jl:20-25): y = exp(-im*dt*f) y0.
+    The HIP path computes in real fp64, so only steps with real -im*dt are accepted here
+    (imaginary-time evolution dt = -1j*tau); real-time steps need the complex128 build."""
+    z = -1j * complex(dt)
+    if abs(z.imag) > 0.0:
+        raise NotImplementedError("real-time evolution needs complex128 tensors (MPSK_C128 is not built yet); "
+                                  "pass dt = -1j*tau for imaginary-time evolution")
+    y, _ = krylov.exponentiate(be, f, z.real, y0, tol=alg.tol, krylovdim=alg.krylovdim, maxiter=alg.maxiter, ws=ws)
+    return y
+
+
+def _timestep_tdvp(psi, H, t, dt, alg: TDVP, envs):  # tdvp.jl:61-94
+    be, L = psi.be, len(psi)
+    ws = krylov.KrylovWorkspace(be)
+    for i in range(L - 1):
+        psi.set_AC(i, integrate(be, ddAC(i, psi, H, envs), psi.AC(i), t, dt / 2, alg, ws))
+        psi.set_CR(i, integrate(be, ddC(i, psi, H, envs), psi.CR(i), t, -dt / 2, alg, ws))
+    psi.set_AC(L - 1, integrate(be, ddAC(L - 1, psi, H, envs), psi.AC(L - 1), t, dt / 2, alg, ws))
+    for i in range(L - 1, 0, -1):
+        psi.set_AC(i, integrate(be, ddAC(i, psi, H, envs), psi.AC(i), t + dt / 2, dt / 2, alg, ws))
+        psi.set_CR(i - 1, integrate(be, ddC(i - 1, psi, H, envs), psi.CR(i - 1), t + dt / 2, -dt / 2, alg, ws))
+    psi.set_AC(0, integrate(be, ddAC(0, psi, H, envs), psi.AC(0), t + dt / 2, dt / 2, alg, ws))
+    return psi, envs
+
+
+def _split_two_site(be, nac2, alg):
+    """tsvd!(nac2; trunc) -> (al, c, ar) with ar[k, s2, b]   (tdvp.jl:124-126)."""
+    Dl, d1, Dr, d2 = nac2.shape
+    trunc_err = alg.trunc_err if alg.trunc_dim <= 0 else 0.0
+    U, S, Vh, k, _ = be.tsvd(nac2.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
+    c = be.upload(np.diag(be.download(DTensor(S.buf, (k,)))))
+    al = DTensor(U.buf, (Dl, d1, k))
+    kmax = Vh.shape[0]
+    ar = be.empty(k, d2, Dr)
+    for s2 in range(d2):
+        be.copy2d(k, Dr, Vh.ptr + 8 * s2 * kmax * Dr, kmax, ar.ptr + 8 * s2 * k, k * d2)
+    return al, c, ar
+
+
+def _timestep_tdvp2(psi, H, t, dt, alg: TDVP2, envs):  # tdvp.jl:113-146
+    be, L = psi.be, len(psi)
+    ws = krylov.KrylovWorkspace(be)
+    for i in range(L - 1):
+        ac2 = _two_site_tensor(be, psi.AC(i), psi.AR(i + 1))
+        al, c, ar = _split_two_site(be, integrate(be, ddAC2(i, psi, H, envs), ac2, t, dt / 2, alg, ws), alg)
+        psi.set_AC(i, (al, c))
+        psi.set_AC(i + 1, (c, ar))
+        if i != L - 2:
+            psi.set_AC(i + 1, integrate(be, ddAC(i + 1, psi, H, envs), psi.AC(i + 1), t, -dt / 2, alg, ws))
+    for i in range(L - 1, 0, -1):
+        ac2 = _two_site_tensor(be, psi.AL(i - 1), psi.AC(i))
+        al, c, ar = _split_two_site(be, integrate(be, ddAC2(i - 1, psi, H, envs), ac2, t + dt / 2, dt / 2, alg, ws), alg)
+        psi.set_AC(i - 1, (al, c))
+        psi.set_AC(i, (c, ar))
+        if i != 1:
+            psi.set_AC(i - 1, integrate(be, ddAC(i - 1, psi, H, envs), psi.AC(i - 1), t + dt / 2, -dt / 2, alg, ws))
+    return psi, envs
+
+
+def _timestep_inf(psi, H, t, dt, alg: TDVP, envs):  # tdvp.jl:21-59 (leftorthflag = true)
+    be, n = psi.be, len(psi)
+    ws = krylov.KrylovWorkspace(be)
+    newAL = []
+    for loc in range(n):
+        ac = integrate(be, ddAC(loc, psi, H, envs), psi.AC[loc], t, dt, alg, ws)
+        c = integrate(be, ddC(loc, psi, H, envs), psi.CR[loc], t, dt, alg, ws)
+        newAL.append(regauge(be, ac, c))
+    psi2 = InfiniteMPS.from_AL(newAL, psi.CR[n - 1], tol=alg.tolgauge, maxiter=alg.gaugemaxiter, be=be)
+    envs.recalculate(psi2)
+    return psi2, envs
+
+
+def timestep(psi, H, t, dt, alg=None, envs=None):
+    """timestep(psi, H, t, dt, alg[, envs]) -> (psi', envs): the copying version (tdvp.jl:148-151)."""
+    alg = TDVP() if alg is None else alg
+    if isinstance(psi, InfiniteMPS):
+        envs = MPOHamInfEnv(psi, H) if envs is None else envs
+        return _timestep_inf(psi, H, t, dt, alg, envs)
+    psi = psi.copy()
+    envs = FinEnv(psi, H) if envs is None else envs
+    if isinstance(alg, TDVP2):
+        return _timestep_tdvp2(psi, H, t, dt, alg, envs)
+    return _timestep_tdvp(psi, H, t, dt, alg, envs)
+
+
+def time_evolve(psi, H, t_span, alg=None, envs=None):
+    """time_evolve(psi, H, t_span, alg[, envs])  (time_evolve.jl:20-40): consecutive timesteps."""
+    alg = TDVP() if alg is None else alg
+    for t0, t1 in zip(t_span[:-1], t_span[1:]):
+        psi, envs = timestep(psi, H, t0, t1 - t0, alg, envs)
+        if alg.finalize is not None:
+            psi, envs = alg.finalize(t0, psi, H, envs)
+    return psi, envs

@@ -112,6 +112,56 @@ def eigsolve_lm_real(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, 
     return float(np.real(lam)), out
 
 
+def exponentiate(be: Backend, matvec, z: float, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
+                 ws: KrylovWorkspace | None = None):
+    """y = exp(z A) x0 for a real symmetric operator and REAL z (KrylovKit.exponentiate as called by
+    integrators.jl:20-25 with z = -im*dt: imaginary-time steps dt = -i tau give z = -tau).
+    Lanczos on device vectors with the fused CGS2 step; the small exp(z T_k) e_1 is formed on the
+    host from the eigendecomposition of T_k; a-posteriori estimate beta_k |e_k^T exp(z T_k) e_1|;
+    if krylovdim is exhausted the step is cut to the converged fraction and restarted.
+    Returns (y, n_matvecs)."""
+    ws = KrylovWorkspace(be) if ws is None else ws
+    shape = x0.shape
+    vecs = ws.get(shape, krylovdim + 2)
+    V, cur = vecs[:krylovdim + 1], vecs[krylovdim + 1]
+    be.axpby(1.0, x0, 0.0, cur)
+    remaining, nmv = 1.0, 0
+    for _ in range(maxiter):
+        nrm = be.norm(cur)
+        if nrm == 0.0 or remaining <= 0.0:
+            break
+        be.axpby(1.0 / nrm, cur, 0.0, V[0])
+        Hm = np.zeros((krylovdim + 1, krylovdim))
+        k, s, u = 0, remaining, None
+        while k < krylovdim:
+            w = V[k + 1]
+            matvec(V[k], w)
+            nmv += 1
+            h, beta = be.orth_step(V[:k + 1], w)
+            Hm[:k + 1, k] = h
+            Hm[k + 1, k] = beta
+            k += 1
+            Tk = (Hm[:k, :k] + Hm[:k, :k].T) / 2
+            ev, S = np.linalg.eigh(Tk)
+            u = S @ (np.exp(remaining * z * ev) * S[0])
+            if beta * abs(u[-1]) <= tol * max(remaining, 1e-300) or beta < 1e-300:
+                s = remaining
+                break
+            if k == krylovdim:
+                s = remaining
+                while True:
+                    u = S @ (np.exp(s * z * ev) * S[0])
+                    if beta * abs(u[-1]) <= tol * s or s < 1e-12:
+                        break
+                    s *= 0.5
+                break
+        be.lincomb(V[:k], nrm * u, out=cur)
+        remaining -= s
+    out = be.empty(*shape)
+    be.axpby(1.0, cur, 0.0, out)
+    return out, nmv
+
+
 def gmres(be: Backend, matvec, b: DTensor, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
           ws: KrylovWorkspace | None = None):
     """Restarted GMRES for matvec(x) = b on device vectors (KrylovKit.linsolve stand-in,

@@ -141,6 +141,22 @@ class FiniteMPS:
         else:
             self.ACs[i] = vec
 
+    def set_CR(self, i, vec):  # CRView.setindex!  orthoview.jl:62-78
+        if self.CLs[i + 1] is None:
+            if self.ALs[i] is not None:
+                C, ar = rightorth(self.be, self.AC(i + 1))
+                self.CLs[i + 1], self.ARs[i + 1] = C, ar
+            else:
+                al, C = leftorth(self.be, self.AC(i))
+                self.ALs[i], self.CLs[i + 1] = al, C
+        self.ACs = [None] * self.N
+        self.CLs = [None] * (self.N + 1)
+        for k in range(i + 1, self.N):
+            self.ALs[k] = None
+        for k in range(0, i + 1):
+            self.ARs[k] = None
+        self.CLs[i + 1] = vec
+
     def set_AC_with_leftorth(self, i, vec):
         """Right-moving site update: the reference computes leftorth(old AC[i]) for calc_galerkin
         (toolbox.jl:20, via AL[i] -> CRView, orthoview.jl:56) and leftorth(new AC[i]) when AL[i] is next

@@ -549,6 +549,56 @@ def gmres(matvec, b, x0, tol=1e-12, krylovdim=30, maxiter=100):
     return x.reshape(shape)
 
 
+def exponentiate(matvec, z, x0, tol=1e-12, krylovdim=30, maxiter=100):
+    """y = exp(z A) x0 for a Hermitian operator A (KrylovKit.exponentiate stand-in used by
+    integrators.jl:20-25: integrate(f, y0, t, dt) = exponentiate(f, -im*dt, y0)).  Lanczos with full
+    reorthogonalisation; the Krylov space grows until the a-posteriori estimate
+    beta_k |e_k^T exp(s z T_k) e_1| drops below tol; if krylovdim is exhausted the step is
+    cut to the fraction s of z that meets the tolerance and the rest restarts from there.
+    Returns (y, n_matvecs)."""
+    shape = x0.shape
+    dt = np.result_type(x0.dtype, type(z), np.float64)
+    y = x0.reshape(-1).astype(dt)
+    remaining, nmv = 1.0, 0
+    for _ in range(maxiter):
+        nrm = np.linalg.norm(y)
+        if nrm == 0 or remaining <= 0:
+            break
+        V = [y / nrm]
+        Hm = np.zeros((krylovdim + 1, krylovdim), dtype=dt)
+        k, s, u = 0, remaining, None
+        while k < krylovdim:
+            w = matvec(V[k].reshape(shape)).reshape(-1).astype(dt)
+            nmv += 1
+            for _r in range(2):
+                for i in range(k + 1):
+                    c = np.vdot(V[i], w)
+                    Hm[i, k] += c
+                    w = w - c * V[i]
+            beta = np.linalg.norm(w)
+            Hm[k + 1, k] = beta
+            k += 1
+            Tk = (Hm[:k, :k] + Hm[:k, :k].conj().T) / 2
+            ev, S = np.linalg.eigh(Tk)
+            u = S @ (np.exp(remaining * z * ev) * S[0].conj())
+            err = beta * abs(u[-1])
+            if err <= tol * max(remaining, 1e-300) or beta < 1e-300:
+                s = remaining
+                break
+            if k == krylovdim:
+                s = remaining
+                while True:     # largest fraction (halving) whose estimate meets its share of the tolerance
+                    u = S @ (np.exp(s * z * ev) * S[0].conj())
+                    if beta * abs(u[-1]) <= tol * s or s < 1e-12:
+                        break
+                    s *= 0.5
+                break
+            V.append(w / beta)
+        y = nrm * sum(u[i] * V[i] for i in range(k))
+        remaining -= s
+    return y.reshape(shape), nmv
+
+
 # --------------------------------------------------------------------------------------
 # FiniteMPS with the lazy-gauge state machine (finitemps.jl:53-169, orthoview.jl:1-143)
 # --------------------------------------------------------------------------------------
@@ -652,6 +702,22 @@ class FiniteMPS:
                 self.CLs[i + 1], self.ALs[i] = b, a
         else:
             self.ACs[i] = vec
+
+    def set_CR(self, i, vec):  # CRView.setindex!  orthoview.jl:62-78
+        if self.CLs[i + 1] is None:
+            if self.ALs[i] is not None:
+                C, ar = rightorth(self.AC(i + 1))
+                self.CLs[i + 1], self.ARs[i + 1] = C, ar
+            else:
+                al, C = leftorth(self.AC(i))
+                self.ALs[i], self.CLs[i + 1] = al, C
+        self.ACs = [None] * self.N
+        self.CLs = [None] * (self.N + 1)
+        for k in range(i + 1, self.N):
+            self.ALs[k] = None
+        for k in range(0, i + 1):
+            self.ARs[k] = None
+        self.CLs[i + 1] = vec
 
     def norm(self):  # finitemps.jl:467
         return np.linalg.norm(self.AC(0))
@@ -832,6 +898,89 @@ def dmrg2(psi, H, truncdim=None, truncerr=1e-6, tol=1e-12, maxiter=100, eig_tol=
         if eps <= tol:
             break
     return psi, envs, eps, log
+
+
+# --------------------------------------------------------------------------------------
+# Time evolution (src/algorithms/timestep/tdvp.jl, integrators.jl, time_evolve.jl)
+# --------------------------------------------------------------------------------------
+
+def integrate(f, y0, t, dt, tol=1e-12, krylovdim=30, maxiter=100):
+    """integrators.jl:20-25 : i dy/dt = f(y)  =>  y(t + dt) = exp(-i dt f) y0.  A purely imaginary
+    dt = -i tau of a real problem stays real (imaginary-time evolution exp(-tau f))."""
+    z = -1j * dt
+    if np.imag(z) == 0 and not np.iscomplexobj(y0):
+        z = float(np.real(z))
+    return exponentiate(f, z, y0, tol=tol, krylovdim=krylovdim, maxiter=maxiter)[0]
+
+
+def tdvp_timestep(psi, H, t, dt, envs=None, tol=1e-12, krylovdim=30):
+    """timestep!(psi::FiniteMPS, H, t, dt, TDVP())  (tdvp.jl:61-94), on a copy (tdvp.jl:148-151)."""
+    psi = psi.copy()
+    envs = FinEnv(psi, H) if envs is None else envs
+    L = len(psi)
+    hac = lambda i: (lambda x: dAC(x, envs.opp[i], envs.leftenv(i, psi), envs.rightenv(i, psi)))
+    hc = lambda i: (lambda x: dC(x, envs.leftenv(i + 1, psi), envs.rightenv(i, psi)))
+    ig = lambda f, y, tt, h: integrate(f, y, tt, h, tol=tol, krylovdim=krylovdim)
+    for i in range(L - 1):
+        psi.set_AC(i, ig(hac(i), psi.AC(i), t, dt / 2))
+        psi.set_CR(i, ig(hc(i), psi.CR(i), t, -dt / 2))
+    psi.set_AC(L - 1, ig(hac(L - 1), psi.AC(L - 1), t, dt / 2))
+    for i in range(L - 1, 0, -1):
+        psi.set_AC(i, ig(hac(i), psi.AC(i), t + dt / 2, dt / 2))
+        psi.set_CR(i - 1, ig(hc(i - 1), psi.CR(i - 1), t + dt / 2, -dt / 2))
+    psi.set_AC(0, ig(hac(0), psi.AC(0), t + dt / 2, dt / 2))
+    return psi, envs
+
+
+def tdvp2_timestep(psi, H, t, dt, envs=None, truncdim=None, truncerr=1e-3, tol=1e-12, krylovdim=30):
+    """timestep!(psi::FiniteMPS, H, t, dt, TDVP2(trscheme))  (tdvp.jl:113-146)."""
+    psi = psi.copy()
+    envs = FinEnv(psi, H) if envs is None else envs
+    L = len(psi)
+    if truncdim is not None:
+        truncerr = None
+    ig = lambda f, y, tt, h: integrate(f, y, tt, h, tol=tol, krylovdim=krylovdim)
+    hac = lambda i: (lambda x: dAC(x, envs.opp[i], envs.leftenv(i, psi), envs.rightenv(i, psi)))
+    hac2 = lambda i: (lambda x: dAC2(x, envs.opp[i], envs.opp[i + 1], envs.leftenv(i, psi),
+                                     envs.rightenv(i + 1, psi)))
+
+    def split(nac2):
+        al, s, ar, _ = tsvd(nac2, truncdim=truncdim, truncerr=truncerr)
+        return al, np.diag(s).astype(nac2.dtype), np.transpose(ar, (0, 2, 1))
+
+    for i in range(L - 1):
+        ac2 = np.einsum("asm,mrb->asbr", psi.AC(i), psi.AR(i + 1))
+        al, c, ar3 = split(ig(hac2(i), ac2, t, dt / 2))
+        psi.set_AC(i, (al, c))
+        psi.set_AC(i + 1, (c, ar3))
+        if i != L - 2:
+            psi.set_AC(i + 1, ig(hac(i + 1), psi.AC(i + 1), t, -dt / 2))
+    for i in range(L - 1, 0, -1):
+        ac2 = np.einsum("asm,mrb->asbr", psi.AL(i - 1), psi.AC(i))
+        al, c, ar3 = split(ig(hac2(i - 1), ac2, t + dt / 2, dt / 2))
+        psi.set_AC(i - 1, (al, c))
+        psi.set_AC(i, (c, ar3))
+        if i != 1:
+            psi.set_AC(i - 1, ig(hac(i - 1), psi.AC(i - 1), t + dt / 2, -dt / 2))
+    return psi, envs
+
+
+def time_evolve(psi, H, t_span, stepper=tdvp_timestep, **kw):
+    """time_evolve(psi, H, t_span, alg)  (time_evolve.jl): consecutive timesteps over t_span."""
+    envs = None
+    for t0, t1 in zip(t_span[:-1], t_span[1:]):
+        psi, envs = stepper(psi, H, t0, t1 - t0, None, **kw)
+    return psi, envs
+
+
+def mps_to_vector(psi):
+    """Dense state vector of a FiniteMPS (for exact checks on short chains)."""
+    v = np.ones((1, 1), dtype=psi.AC(0).dtype)
+    L = len(psi)
+    for i in range(L):
+        A = psi.AL(i) if i < L - 1 else psi.AC(L - 1)
+        v = np.tensordot(v, A, axes=([v.ndim - 1], [0])).reshape(-1, A.shape[2])
+    return v.reshape(-1)
 
 
 # --------------------------------------------------------------------------------------

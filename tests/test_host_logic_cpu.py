@@ -115,3 +115,32 @@ def test_mpohamiltonian_from_twosite_matches_oracle(cb):
     Hg, Ho = mk.from_twosite(h2, be=cb), mo.tfi_twosite_mpo(0.8)
     assert Hg[0].chil == Ho[0].chil
     assert np.abs(Hg[0].oracle.full() - Ho[0].full()).max() < 1e-12
+
+
+def test_tdvp_driver_matches_oracle(cb):
+    """tdvp.jl:61-94 on the product's host code (CRView.setindex!, integrate, exponentiate) == oracle,
+    imaginary-time step at truncated bond dimension; exact vs dense expm at full bond dimension."""
+    import scipy.linalg as sla
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=cb), mo.heisenberg_mpo(0.5)
+    pg, po = _pair(cb, L=6, D=4, seed=9)
+    p1, e1 = mk.timestep(pg, Hg, 0.0, -0.1j, mk.TDVP())
+    q1, f1 = mo.tdvp_timestep(po, Ho, 0.0, -0.1j)
+    assert abs(p1.norm() - q1.norm()) < 1e-11
+    Eg = float(np.sum(mk.expectation_value(p1, Hg, e1)))
+    Eo = float(np.sum(mo.expectation_value(q1, Ho, f1)).real)
+    assert abs(Eg - Eo) < 1e-10 * abs(Eo)
+    for i in range(6):
+        assert np.abs(cb.download(p1.AC(i)) - q1.AC(i)).max() < 1e-10
+    # full bond dimension: exact
+    pg, po = _pair(cb, L=6, D=64, seed=10)
+    v0 = mo.mps_to_vector(po)
+    p1, _ = mk.timestep(pg, Hg, 0.0, -0.2j, mk.TDVP())
+    host = mo.FiniteMPS.__new__(mo.FiniteMPS)
+    vec = np.ones((1, 1))
+    for i in range(6):
+        A = cb.download(p1.AL(i)) if i < 5 else cb.download(p1.AC(5))
+        vec = np.tensordot(vec, A, axes=([vec.ndim - 1], [0])).reshape(-1, A.shape[2])
+    ex = sla.expm(-0.2 * mo.dense_hamiltonian(Ho, 6)) @ v0
+    assert np.abs(vec.reshape(-1) - ex).max() < 1e-11
+    with pytest.raises(NotImplementedError):
+        mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP())

@@ -153,3 +153,35 @@ def test_golden_vectors_regression():
     assert np.abs(np.stack(mo.transfer_right(GR, H, g["A_A"], g["A_Ab"])) - g["A_tr"]).max() < 1e-12
     q, r = mo.qrpos(g["G_M"])
     assert np.abs(q - g["G_Q"]).max() < 1e-12 and np.abs(r - g["G_R"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("dt", [0.1, -0.1j, 0.05 - 0.02j])
+def test_tdvp_exact_at_full_bond_dimension(dt):
+    """Pins the oracle's TDVP / TDVP2 / exponentiate restatement (tdvp.jl:61-146, integrators.jl:20-25):
+    the projector-splitting integrator is EXACT when the bond dimension is not truncated, so one
+    timestep must reproduce the dense exp(-i dt H) psi0 (real, imaginary and mixed time)."""
+    import scipy.linalg as sla
+    L = 6
+    H = mo.heisenberg_mpo(0.5)
+    Hd = mo.dense_hamiltonian(H, L)
+    psi = mo.FiniteMPS.random(L, 2, 64, np.random.default_rng(1))
+    v0 = mo.mps_to_vector(psi)
+    if np.real(dt) != 0:
+        psi = mo.FiniteMPS([psi.AL(i).astype(complex) for i in range(L - 1)] + [psi.AC(L - 1).astype(complex)])
+    ex = sla.expm(-1j * dt * Hd) @ v0
+    p1, _ = mo.tdvp_timestep(psi, H, 0.0, dt)
+    assert np.abs(mo.mps_to_vector(p1) - ex).max() < 1e-12
+    p2, _ = mo.tdvp2_timestep(psi, H, 0.0, dt, truncdim=64)
+    assert np.abs(mo.mps_to_vector(p2) - ex).max() < 1e-12
+
+
+def test_tdvp_real_time_conserves_energy():
+    """test/algorithms.jl:96-110 : E(psi(dt)) == E(psi0) for a (truncated-D) real-time TDVP step."""
+    L = 8
+    H = mo.heisenberg_mpo(0.5)
+    psi = mo.FiniteMPS.random(L, 2, 6, np.random.default_rng(3), dtype=np.complex128)
+    e0 = np.sum(mo.expectation_value(psi, H, mo.FinEnv(psi, H))).real
+    p1, envs = mo.tdvp_timestep(psi, H, 0.0, 0.1)
+    e1 = np.sum(mo.expectation_value(p1, H, envs)).real
+    assert abs(e1 - e0) < 1e-8 * max(1.0, abs(e0))
+    assert abs(p1.norm() - 1) < 1e-10
