@@ -56,6 +56,11 @@ int mpsk_ctx_workspace_reserve(mpsk_ctx* ctx, size_t bytes);   /* pre-size the p
  * flags an ill-conditioned / rank-deficient input), 1 Householder only, 2 CholeskyQR3 only (error on flag) */
 int mpsk_ctx_set_qr_mode(mpsk_ctx* ctx, int mode);
 int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallback);
+/* tsvd algorithm switch: precondition = 1 (default) factors the tall orientation of theta with QRpos first and
+ * runs the block-Jacobi iteration on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra),
+ * 0 = Jacobi on theta directly.  mpsk_ctx_svd_stats returns the number of Jacobi sweeps of the last mpsk_tsvd. */
+int mpsk_ctx_set_svd_mode(mpsk_ctx* ctx, int precondition);
+int mpsk_ctx_svd_stats(mpsk_ctx* ctx, int* last_sweeps);
 /* tile override for benchmarking the GEMM core (0,0 restores the heuristic) */
 int mpsk_ctx_force_tile(mpsk_ctx* ctx, int bm, int bn);
 

@@ -83,6 +83,14 @@ class Backend:
         check(self.lib.mpsk_ctx_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(f)), "mpsk_ctx_qr_stats")
         return {"cholqr3": a.value, "householder": b.value, "fallback": f.value}
 
+    def set_svd_mode(self, precondition=True):
+        check(self.lib.mpsk_ctx_set_svd_mode(self.ctx, int(bool(precondition))), "mpsk_ctx_set_svd_mode")
+
+    def svd_sweeps(self):
+        n = C.c_int()
+        check(self.lib.mpsk_ctx_svd_stats(self.ctx, C.byref(n)), "mpsk_ctx_svd_stats")
+        return n.value
+
     def prof_enable(self, on=True):
         check(self.lib.mpsk_prof_enable(self.ctx, int(on)), "mpsk_prof_enable")
 

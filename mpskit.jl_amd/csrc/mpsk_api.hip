@@ -44,6 +44,7 @@ struct mpsk_ctx {
   double* d_partial = nullptr;  // dot scratch
   double* h_scal = nullptr;     // pinned host mirror
   int last_svd_sweeps = 0;
+  int svd_precondition = 1;     // QR-preconditioned Jacobi (mpsk_ctx_set_svd_mode)
   int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
   int* d_flag = nullptr;
   long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0;
@@ -615,11 +616,45 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
   REQUIRE(ldt >= m && ldu >= m && ldv >= kmax, "leading dimension too small");
   REQUIRE(trunc_err >= 0.0, "trunc_err must be >= 0");
   HIPCHK(hipSetDevice(c->device));
-  if (int rc = ensure_ws(c, tsvd_workspace_bytes(m, n))) return rc;
   std::string err;
+  const int mm = m < n ? n : m, nn = m < n ? m : n, transposed = m < n ? 1 : 0;
+  if (c->svd_precondition && nn > 64) {
+    // QR-preconditioned one-sided Jacobi: A' = theta or theta^T (tall) = Qb Rb, Jacobi on Rb^T
+    const auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };   // keep every sub-buffer 16-byte aligned
+    const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);
+    const size_t qws = sizeof(double) * qr_ws_doubles(mm, nn), sws = tsvd_workspace_bytes(nn, nn);
+    if (int rc = ensure_ws(c, sizeof(double) * (a_d + q_d + r_d) + (qws > sws ? qws : sws) + 256)) return rc;
+    double* At = (double*)c->ws;
+    double* Qb = At + a_d;
+    double* Rb = Qb + q_d;
+    double* rest = Rb + r_d;
+    const double* Ap = (const double*)theta;
+    int lda = ldt;
+    if (transposed) {
+      HIPCHK(transpose((const double*)theta, ldt, m, n, At, mm, c->stream));
+      Ap = At; lda = mm;
+    }
+    if (int rc = qrpos_dispatch(c, mm, nn, Ap, lda, Qb, mm, Rb, nn, rest)) return rc;
+    hipError_t e = tsvd(nn, nn, Rb, nn, (double*)U, ldu, (double*)S, (double*)Vh, ldv, max_keep, trunc_err, kept,
+                        disc_norm, rest, c->stream, &err, &c->last_svd_sweeps, Qb, mm, mm, transposed, c->stream2);
+    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + hipGetErrorString(e));
+    return MPSK_OK;
+  }
+  if (int rc = ensure_ws(c, tsvd_workspace_bytes(m, n))) return rc;
   hipError_t e = tsvd(m, n, (const double*)theta, ldt, (double*)U, ldu, (double*)S, (double*)Vh, ldv, max_keep,
-                      trunc_err, kept, disc_norm, c->ws, c->stream, &err, &c->last_svd_sweeps);
+                      trunc_err, kept, disc_norm, c->ws, c->stream, &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->stream2);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + hipGetErrorString(e));
+  return MPSK_OK;
+}
+
+int mpsk_ctx_set_svd_mode(mpsk_ctx* c, int precondition) {
+  REQUIRE(c, "ctx is NULL");
+  c->svd_precondition = precondition ? 1 : 0;
+  return MPSK_OK;
+}
+int mpsk_ctx_svd_stats(mpsk_ctx* c, int* last_sweeps) {
+  REQUIRE(c && last_sweeps, "NULL argument");
+  *last_sweeps = c->last_svd_sweeps;
   return MPSK_OK;
 }
 

@@ -12,7 +12,7 @@
 //   epilogue writes full 128-B lines.
 // * LDS images are padded so that ds_read_b64 fragment reads are bank-conflict free:
 //     MN-major image [BK][BMN+16]   (k-row stride == 128 B mod 256 B)
-//     K-major  image [BMN][BK+2]    (row stride 144 B: 16 rows hit 16 distinct 16-B slots)
+//     K-major  image [BMN][BK]      (128-B rows, column index XOR-swizzled by the row)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdio>
@@ -31,9 +31,13 @@ constexpr int BK = 16;
 constexpr int NTHREADS = 256;
 
 template <int BMN, bool KMAJOR> struct LdsImg {
-  static constexpr int STRIDE = KMAJOR ? (BK + 2) : (BMN + 16);
-  static constexpr int SIZE = KMAJOR ? BMN * (BK + 2) : BK * (BMN + 16);  // doubles
-  __device__ static inline int idx(int mn, int k) { return KMAJOR ? mn * STRIDE + k : k * STRIDE + mn; }
+  static_assert(BK == 16, "the K-major swizzle assumes 128-byte rows");
+  static constexpr int STRIDE = KMAJOR ? BK : (BMN + 16);
+  static constexpr int SIZE = KMAJOR ? BMN * BK : BK * (BMN + 16);  // doubles
+  // K-major rows are 128 B, unpadded, with the 8-byte column index XOR-swizzled by the row: the 16 rows
+  // a fragment read touches at one k land on 16 distinct bank pairs under BOTH banking rules the
+  // compiler may pick (ds_read_b64: 32 lanes / 64 banks; ds_read2_b64: 16 lanes / 32 banks).
+  __device__ static inline int idx(int mn, int k) { return KMAJOR ? mn * BK + (k ^ (mn & 15)) : k * STRIDE + mn; }
 };
 
 // Loader for one operand tile (BMN x BK).  KCONTIG: element (mn,k) at base[k + mn*ld], else
@@ -82,7 +86,13 @@ template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
       int mn, k;
       if (KCONTIG) { k = (v % (BK / 2)) * 2; mn = v / (BK / 2); }
       else         { mn = (v % (BMN / 2)) * 2; k = v / (BMN / 2); }
-      *reinterpret_cast<d2*>(&lds[Img::idx(mn, k)]) = r[i];
+      if (KCONTIG) {   // (k, k+1), k even, share one 16-B slot of the swizzled row; odd rows swap the halves
+        d2 v = r[i];
+        if (mn & 1) v = d2{v.y, v.x};
+        *reinterpret_cast<d2*>(&lds[Img::idx(mn, k) & ~1]) = v;
+      } else {
+        *reinterpret_cast<d2*>(&lds[Img::idx(mn, k)]) = r[i];
+      }
     }
   }
 };
@@ -139,11 +149,15 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[nb][j] = b_s[IB::idx(wn * WTN + j * 16 + fr, ks + 4 + fq)];
       }
+      // keep the next k-step's ds_reads ABOVE this k-step's MFMAs (the machine scheduler otherwise sinks
+      // them to their use and every MFMA group starts with s_waitcnt lgkmcnt(0) on a just-issued read)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < kte) {
       la.store(sA + (cur ^ 1) * IA::SIZE, tid);
@@ -474,6 +488,7 @@ static hipError_t launch_tile(const GemmArgs& g, int bm, int bn, hipStream_t s) 
 static void choose_tile(int M, int N, int batch, int* bm, int* bn) {
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
   for (int c = 0; c < 4; ++c) {
+    if ((M <= 64 && cand[c][0] > 64) || (N <= 64 && cand[c][1] > 64)) continue;   // never pad a 64-wide side to 128
     int64_t tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
     if (tm * tn * batch >= 6 * 256 || c == 3) { *bm = cand[c][0]; *bn = cand[c][1]; return; }
   }

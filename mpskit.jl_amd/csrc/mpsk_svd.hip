@@ -38,7 +38,7 @@ __device__ __forceinline__ double sv_readlane(double v, int lane) {
 
 __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restrict__ Mpart, int Q,
                                                          double* __restrict__ Wout, double tol,
-                                                         unsigned long long* __restrict__ flag) {
+                                                         unsigned long long* __restrict__ flag, int inner_sweeps) {
   __shared__ double Ms[J2][J2 + 1];
   __shared__ double Ws[J2][J2 + 1];
   __shared__ double cs_c[J2 / 2], cs_s[J2 / 2];
@@ -174,8 +174,13 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
     __syncthreads();
   }
   // (2) one-sided Jacobi on R = Ms (upper triangular), W = Ws
-  const int pk = tid >> 3, pj = tid & 7;
-  for (int sweep = 0; sweep < 3; ++sweep) {
+  // Pair index of this 8-lane team.  Teams that share a 32-lane LDS read group (16-lane write group) get
+  // pair indices 8 apart: their columns pp = (st + pk) % 63 then sit 8 apart too, so the four 8-row
+  // segments {col + pj} tile the 32 bank pairs instead of piling onto the same ones (consecutive pk:
+  // ~4-way conflicts on all 64 LDS accesses of a step, 3000 cycles/step).
+  const int team = tid >> 3, pj = tid & 7;
+  const int pk = ((team & 3) << 3) | (team >> 2);
+  for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
     if (tid == 0) any_rot = 0;
     __syncthreads();
     int rotated = 0;
@@ -209,7 +214,11 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
         int ex;
         (void)frexp(fmax(fabs(num), fabs(ga)), &ex);       // common power-of-two scale: no fp32 over/underflow
         const float zf = (float)ldexp(num, -ex) * __frcp_rn((float)ldexp(ga, -ex));
-        const float tf = copysignf(1.0f, zf) * __frcp_rn(fabsf(zf) + __fsqrt_rn(1.0f + zf * zf));
+        // |zeta| > 1e4: sqrt(1 + zeta^2) == |zeta| in fp32 and zeta^2 would overflow for graded column pairs
+        // (norm ratio x cosine < 1e-19) -- those rotations were silently dropped (t = 1/inf) and the sweep
+        // count ran to the cap; t = 1 / (2 zeta) there.
+        const float az = fabsf(zf);
+        const float tf = copysignf(1.0f, zf) * (az > 1.0e4f ? 0.5f * __frcp_rn(az) : __frcp_rn(az + __fsqrt_rn(1.0f + zf * zf)));
         const double t = (double)tf;
         const double x = 1.0 + t * t;
         double r = (double)__frsqrt_rn((float)x);
@@ -217,8 +226,8 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
         r = r * (1.5 - 0.5 * x * r * r);
         c = r;
         sn = r * t;
-        if (gg > 5.3e-32 * ab) rotated = 1;
-      }
+        if (gg > 1.0e-20 * ab) rotated = 1;   // |cos| > 1e-10: another inner sweep is worth it (quadratic
+      }                                        // convergence; the OUTER loop re-measures every pair anyway)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int r = pj + 8 * i;
@@ -236,21 +245,60 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
   }
   // One Newton-Schulz step  W <- W (3 I - W^T W) / 2  removes the O(#rotations * eps) drift of
   // W's orthogonality, so the accumulated V (and G = theta V) stay orthogonal over ~10^3 rounds.
+  // Both 64^3 products run on the matrix cores (4 waves x 2x2 tiles of 16x16).
   __syncthreads();
-  for (int e = tid; e < J2 * J2; e += 256) {
-    const int i = e % J2, j = e / J2;
-    double t = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < J2; ++r) t += Ws[r][i] * Ws[r][j];
-    Ms[i][j] = t;
-  }
-  __syncthreads();
-  for (int e = tid; e < J2 * J2; e += 256) {
-    const int i = e % J2, j = e / J2;
-    double t = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < J2; ++r) t += Ws[i][r] * Ms[r][j];
-    Wp[e] = 1.5 * Ws[i][j] - 0.5 * t;
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, fq = lane >> 4, fr = lane & 15;
+    sv_d4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = sv_d4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < J2; k0 += 4) {       // T = W^T W
+      double af[2], bf[2];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) af[ti] = Ws[k0 + fq][32 * wr + 16 * ti + fr];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) bf[tj] = Ws[k0 + fq][32 * wc + 16 * tj + fr];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Ms[32 * wr + 16 * ti + fq + 4 * rg][32 * wc + 16 * tj + fr] = acc[ti][tj][rg];
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = sv_d4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < J2; k0 += 4) {       // P = W T
+      double af[2], bf[2];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) af[ti] = Ws[32 * wr + 16 * ti + fr][k0 + fq];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) bf[tj] = Ms[k0 + fq][32 * wc + 16 * tj + fr];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int i = 32 * wr + 16 * ti + fq + 4 * rg, j = 32 * wc + 16 * tj + fr;
+          Wp[i + J2 * j] = 1.5 * Ws[i][j] - 0.5 * acc[ti][tj][rg];
+        }
   }
 }
 
@@ -312,7 +360,7 @@ static SvdPlan svd_plan(int m, int n) {
   p.nn = p.transposed ? m : n;
   p.npad = ((p.nn + J2 - 1) / J2) * J2;
   p.P = p.npad / J2;
-  int target = 512 / p.P;            // aim at ~512 Gram tiles per round
+  int target = 1024 / p.P;           // aim at ~1024 Gram tiles per round (and k-tiles too short for split-K)
   if (target < 1) target = 1;
   if (target > 16) target = 16;
   int q = 1;                         // largest divisor of mm <= target with >= 128 (even) rows per split
@@ -320,7 +368,7 @@ static SvdPlan svd_plan(int m, int n) {
     if (p.mm % c == 0 && (p.mm / c) % 2 == 0 && p.mm / c >= 128) { q = c; break; }
   p.Q = q;
   size_t d = (size_t)2 * p.mm * p.npad + (size_t)2 * p.nn * p.npad + (size_t)p.P * p.Q * J2 * J2 +
-             (size_t)p.P * J2 * J2 + (size_t)p.npad * 2 + 64;
+             (size_t)2 * p.P * J2 * J2 + (size_t)p.npad * 2 + 64;
   size_t tabs = (size_t)8 * (2 * p.P) * sizeof(int64_t) + (size_t)p.P * p.Q * 2 * sizeof(int64_t) + 256;
   p.bytes = d * sizeof(double) + tabs + (size_t)p.npad * sizeof(int);
   return p;
@@ -329,10 +377,21 @@ static SvdPlan svd_plan(int m, int n) {
 size_t tsvd_workspace_bytes(int m, int n) { return svd_plan(m, n).bytes; }
 
 // Host-synchronising truncated SVD; see include/mpsk.h (mpsk_tsvd) for the contract.
+//
+// QR-preconditioned mode (Qpre != nullptr; Drmac-Veselic): the caller factored the tall orientation
+// A' (q_rows x n, = theta or theta^T) as A' = Qpre R and passes theta := R (n x n, m == n).  Jacobi then runs
+// on the columns of R^T, which are far closer to orthogonal than those of A' (graded spectra -- the DMRG
+// case -- stagnate for tens of sweeps without it):  R^T = G W^T  =>  A' = (Qpre W) Sigma (G Sigma^-1)^T.
+// outer_transposed says whether A' was theta^T, i.e. which factor is U and which is Vh.
 hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
                 int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,
-                std::string* err, int* sweeps_out) {
-  const SvdPlan pl = svd_plan(m, n);
+                std::string* err, int* sweeps_out, const double* Qpre, int ldq, int q_rows, int outer_transposed,
+                hipStream_t s2) {
+  SvdPlan pl = svd_plan(m, n);
+  if (Qpre) {
+    if (m != n) return hipErrorInvalidValue;
+    pl.transposed = 1;                    // G <- R^T
+  }
   const int mm = pl.mm, nn = pl.nn, npad = pl.npad, P = pl.P, Q = pl.Q;
   const int kmax = std::min(m, n);
   double* G[2]; double* V[2];
@@ -341,7 +400,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   V[0] = G[1] + (size_t)mm * npad; V[1] = V[0] + (size_t)nn * npad;
   double* Mpart = V[1] + (size_t)nn * npad;
   double* Wm = Mpart + (size_t)P * Q * J2 * J2;
-  double* sigma2 = Wm + (size_t)P * J2 * J2;
+  double* sigma2 = Wm + (size_t)2 * P * J2 * J2;      // Wm is double-buffered (see the round loop)
   double* scale = sigma2 + npad;
   unsigned long long* flag = (unsigned long long*)(scale + npad);
   int64_t* tabs = (int64_t*)(flag + 8);
@@ -394,11 +453,30 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   const bool kq_even = (kq % 2 == 0) && (mm % 2 == 0) && (nn % 2 == 0);
   const double tol = std::sqrt((double)mm) * 2.220446049250313e-16;
   int cur = 0, sweeps = 0;
+  // One cyclic inner sweep per visit of a pair is enough: measured on MI355X the outer sweep count does not
+  // change (4096^2: 14-15 sweeps with 1, 2 or 3 inner sweeps) while the eig kernel time drops 2.5x.  A single
+  // pair (n <= 64) has no outer tournament, so it keeps the full inner iteration.
+  int inner_sweeps = (P == 1) ? 3 : 1;
+  if (const char* ev = getenv("MPSK_SVD_INNER")) { inner_sweeps = atoi(ev); if (inner_sweeps < 1) inner_sweeps = 1; }
   const int rounds = (P == 1) ? 1 : 2 * P - 1;
   unsigned long long hflag = 0;
+  // Two streams: the V accumulation of round r (bandwidth-bound, needs only W_r) runs on s2 while the main
+  // stream already forms the Gram matrices / rotations of round r+1 (latency-bound, 1 workgroup per pair).
+  // W is double-buffered; evW[b]: W_b written (s -> s2), evV[b]: W_b consumed by the V update (s2 -> s).
+  if (!s2) s2 = s;
+  hipEvent_t evW[2], evV[2];
+  for (int b = 0; b < 2; ++b) {
+    if ((e = hipEventCreateWithFlags(&evW[b], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&evV[b], hipEventDisableTiming)) != hipSuccess) return e;
+  }
+  auto drop_events = [&]() { for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(evW[b]); (void)hipEventDestroy(evV[b]); } };
+  long rc = 0;                              // global round counter
+  int vcur = 0;
   for (int sweep = 0; sweep < 40; ++sweep) {
-    if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
-    for (int r = 0; r < rounds; ++r) {
+    if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) { drop_events(); return e; }
+    for (int r = 0; r < rounds; ++r, ++rc) {
+      const int wb = (int)(rc & 1);
+      double* Wb = Wm + (size_t)wb * P * J2 * J2;
       // 1. Gram (TN): M[p][q] = X_p[rows of split q]^T X_p[rows of split q]
       GemmArgs g;
       std::memset(&g, 0, sizeof(g));
@@ -406,29 +484,39 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       g.batch = P * Q; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = 1; g.transB = 0;
       g.tabA = t_gramA; g.tabB = t_gramA; g.tabC = t_gramC; g.tabs_even = kq_even;
       g.K = kq;
-      if ((e = gemm_f64(g, s)) != hipSuccess) return e;
-      // 2. eigen-decomposition of each 64x64 Gram matrix
-      hipLaunchKernelGGL(jacobi_eig_kernel, dim3(P), dim3(256), 0, s, Mpart, Q, Wm, tol, flag);
-      // 3. updates into next round's slots
+      if ((e = gemm_f64(g, s)) != hipSuccess) { drop_events(); return e; }
+      // 2. rotations of each 64-column pair (W_b may still be read by the V update of round rc - 2)
+      if (rc >= 2 && s2 != s) (void)hipStreamWaitEvent(s, evV[wb], 0);
+      hipLaunchKernelGGL(jacobi_eig_kernel, dim3(P), dim3(256), 0, s, Mpart, Q, Wb, tol, flag, inner_sweeps);
+      if (s2 != s) (void)hipEventRecord(evW[wb], s);
+      // 3. updates into next round's slots: G on the main stream, V on s2
       GemmArgs u;
       std::memset(&u, 0, sizeof(u));
-      u.B = Wm; u.N = J2; u.K = J2; u.ldb = J2; u.batch = P; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
+      u.B = Wb; u.N = J2; u.K = J2; u.ldb = J2; u.batch = P; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
       u.tabB = t_updB; u.tabs_even = kq_even; u.splitN = JB;
       u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G; u.tabC = t_updC_G;
       u.tabC2 = t_updC_G + P;
-      if ((e = gemm_f64(u, s)) != hipSuccess) return e;
-      u.A = V[cur]; u.C = V[cur ^ 1]; u.M = nn; u.lda = nn; u.ldc = nn; u.tabA = t_updA_V; u.tabC = t_updC_V;
+      if ((e = gemm_f64(u, s)) != hipSuccess) { drop_events(); return e; }
+      if (s2 != s) (void)hipStreamWaitEvent(s2, evW[wb], 0);
+      u.A = V[vcur]; u.C = V[vcur ^ 1]; u.M = nn; u.lda = nn; u.ldc = nn; u.tabA = t_updA_V; u.tabC = t_updC_V;
       u.tabC2 = t_updC_V + P;
-      if ((e = gemm_f64(u, s)) != hipSuccess) return e;
+      if ((e = gemm_f64(u, s2)) != hipSuccess) { drop_events(); return e; }
+      if (s2 != s) (void)hipEventRecord(evV[wb], s2);
       cur ^= 1;
+      vcur ^= 1;
     }
     ++sweeps;
-    if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) { drop_events(); return e; }
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) { drop_events(); return e; }
     double mx;
     std::memcpy(&mx, &hflag, sizeof(double));
+    if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] sweep %d: max |cos| = %.3e (tol %.1e)\n", sweeps, mx, tol);
     if (mx <= tol) break;
   }
+  if (s2 != s) {                            // join: everything below runs on s and reads V
+    if ((e = hipStreamSynchronize(s2)) != hipSuccess) { drop_events(); return e; }
+  }
+  drop_events();
   if (sweeps_out) *sweeps_out = sweeps;
   if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] %d x %d: P=%d Q=%d rounds/sweep=%d sweeps=%d\n", mm, nn, P, Q, rounds, sweeps);
 
@@ -459,7 +547,24 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   if ((e = hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(scale, sc.data(), sizeof(double) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(S, sv.data(), sizeof(double) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
-  if (!pl.transposed) {
+  if (Qpre) {
+    double* Vp = G[cur ^ 1];              // the idle ping-pong buffer holds W[:, perm]  (n x kmax)
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, V[cur], nn, nn, d_perm, (const double*)nullptr,
+                       kmax, Vp, nn, 0);
+    GemmArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.batch = 1; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.K = nn;
+    if (!outer_transposed) {              // U = Qpre W_p ; Vh = (G_p Sigma^-1)^T
+      g.A = Qpre; g.lda = ldq; g.B = Vp; g.ldb = nn; g.C = U; g.ldc = ldu; g.M = q_rows; g.N = kmax;
+      if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+      hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, G[cur], mm, nn, d_perm, scale, kmax, Vh, ldv, 1);
+    } else {                              // U = G_p Sigma^-1 ; Vh = (Qpre W_p)^T = W_p^T Qpre^T
+      hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, G[cur], mm, nn, d_perm, scale, kmax, U, ldu, 0);
+      g.A = Vp; g.lda = nn; g.transA = 1; g.B = Qpre; g.ldb = ldq; g.transB = 1; g.C = Vh; g.ldc = ldv;
+      g.M = kmax; g.N = q_rows;
+      if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+    }
+  } else if (!pl.transposed) {
     hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, G[cur], mm, m, d_perm, scale, kmax, U, ldu, 0);
     hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, V[cur], nn, n, d_perm, (const double*)nullptr,
                        kmax, Vh, ldv, 1);

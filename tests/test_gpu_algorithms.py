@@ -237,7 +237,7 @@ def test_tdvp2_truncating_matches_oracle(be):
     es = []
     psi, envs = pg, None
     for k in range(4):
-        psi, envs = mk.time_evolve(psi, Hg, [0.0, 0.1, 0.2], mk.TDVP(), envs)
+        psi, envs = mk.time_evolve(psi, Hg, [0.0, -0.1j, -0.2j], mk.TDVP(), envs)
         es.append(float(np.sum(mk.expectation_value(psi, Hg, envs))))
     assert all(b < a + 1e-12 for a, b in zip(es, es[1:]))
 

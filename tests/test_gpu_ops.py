@@ -286,3 +286,57 @@ def test_tsvd_truncation_and_small_singular_values(be):
     _, So, _, erro = mo.tsvd(A.reshape(m, 1, n, 1), truncerr=eps)
     assert kept2 == len(So)
     assert abs(disc2 - erro) < 1e-13
+
+
+@pytest.mark.parametrize("m,n", [(100, 37), (37, 100), (300, 300), (640, 256), (256, 640)])
+def test_tsvd_plain_mode_matches_preconditioned(be, m, n):
+    """mpsk_ctx_set_svd_mode(0): Jacobi on theta itself -- same contract as the default QR-preconditioned path."""
+    rng = np.random.default_rng(m + 7 * n)
+    A = rng.random((m, n))
+    k = min(m, n)
+    Sr = np.linalg.svd(A, compute_uv=False)
+    try:
+        for mode in (False, True):
+            be.set_svd_mode(mode)
+            U, S, Vh, kept, disc = be.tsvd(be.upload(A))
+            U, S, Vh = be.download(U), be.download(S), be.download(Vh)
+            assert kept == k and np.abs(S - Sr).max() < 1e-12 * Sr[0]
+            assert np.abs(U.T @ U - np.eye(k)).max() < 1e-12 and np.abs(Vh @ Vh.T - np.eye(k)).max() < 1e-12
+            assert relerr((U * S) @ Vh, A) < 1e-12
+    finally:
+        be.set_svd_mode(True)
+
+
+def test_tsvd_graded_and_rank_deficient_preconditioned(be):
+    """The DMRG case: Schmidt-like spectrum over 14 decades behind random orthogonal factors, plus an exactly
+    rank-deficient theta (QRpos falls back to Householder, R^T has zero columns).  The preconditioned
+    iteration needs few sweeps where plain block Jacobi needs tens."""
+    rng = np.random.default_rng(5)
+    m, n = 640, 512
+    Uo, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    Vo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.logspace(0, -14, n)
+    A = (Uo * s) @ Vo.T
+    U, S, Vh, kept, disc = be.tsvd(be.upload(A), max_keep=128)
+    sw_pre = be.svd_sweeps()
+    S = be.download(S)
+    assert np.abs(S[:n] - s).max() < 2e-14
+    U, Vh = be.download(U)[:, :kept], be.download(Vh)[:kept]
+    assert np.abs(U.T @ U - np.eye(kept)).max() < 1e-12 and np.abs(Vh @ Vh.T - np.eye(kept)).max() < 1e-12
+    assert relerr((U * S[:kept]) @ Vh, (Uo[:, :128] * s[:128]) @ Vo[:, :128].T) < 1e-12
+    try:
+        be.set_svd_mode(False)
+        _, S0, _, _, _ = be.tsvd(be.upload(A), max_keep=128)
+        sw_plain = be.svd_sweeps()
+        assert np.abs(be.download(S0)[:n] - s).max() < 1e-12   # plain block Jacobi stalls on graded input (sweep cap)
+    finally:
+        be.set_svd_mode(True)
+    assert sw_pre <= 12 and sw_pre < sw_plain, (sw_pre, sw_plain)
+    # exact rank deficiency: rank 100 of 256
+    B = rng.standard_normal((384, 100)) @ rng.standard_normal((100, 256))
+    U, S, Vh, kept, disc = be.tsvd(be.upload(B))
+    U, S, Vh = be.download(U), be.download(S), be.download(Vh)
+    Sr = np.linalg.svd(B, compute_uv=False)
+    assert np.abs(S - Sr).max() < 1e-12 * Sr[0]
+    assert relerr((U * S) @ Vh, B) < 1e-12
+    assert np.abs(U[:, :100].T @ U[:, :100] - np.eye(100)).max() < 1e-12

@@ -38,6 +38,13 @@ def main():
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
             print(f"D={D} d={d} W={W} tile={tile}: {ms:.3f} ms  {flops_dAC(D, d, W) / ms * 1e-9:.2f} TFLOP/s", flush=True)
+            if os.environ.get("MPSK_BENCH_PROF"):
+                be.prof_enable(True)
+                for _ in range(5):
+                    be.dAC(H, GL, GR, x, out=y)
+                for r in be.prof_summary():
+                    print(f"    {r['kernel']}: {r['avg_ms']*1e3:.1f} us  {r['flops']/r['launches']/r['avg_ms']*1e-9:.1f} TF/s")
+                be.prof_enable(False)
         be.lib.mpsk_ctx_force_tile(be.ctx, 0, 0)
 
 main()
