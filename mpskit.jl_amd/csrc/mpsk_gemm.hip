@@ -542,7 +542,10 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
         if (ws) { bm = bn = 128; g.sk_units = (int)((Ub + 511) / 512); g.sk_ws = ws; }
       }
     }
-    if (g.sk_units == 0 && g_splitk_enabled && bm == 64 && bn == 64 && Ts <= 512 && KT >= 32) {
+    // (the fixed-order fixup is a second, dependent launch of ~18 us: below ~64 k-tiles the split loses.  An
+    //  in-kernel fixup by the last-arriving share was measured and rejected: its agent-scope release/acquire
+    //  fences write back / invalidate the XCD's L2 and cost 45 % on the big dAC stage.)
+    if (g.sk_units == 0 && g_splitk_enabled && bm == 64 && bn == 64 && Ts <= 512 && KT >= 64) {
       // split-K for long-K GEMMs with too few 64x64 tiles to fill the chip (<= 2 workgroups per CU):
       // f shares per tile through the stream-K body (first share writes C, the others a workspace
       // slot, fixed-order fixup).  E.g. stage 3 of dAC at D = 1024: 512 tiles x 320 k-tiles -> f = 2.

@@ -60,6 +60,46 @@ def c4(be):
     print(f"c4 dAC2 D=1024 d=4 W=6: {dt * 1e3:.2f} ms = {fl / dt / 1e12:.1f} TFLOP/s (algorithmic {fl / 1e9:.0f} GF)", flush=True)
 
 
+def c4sweep(be, L=16, D=256):
+    """Two-site DMRG sweeps (Hubbard U/t = 4, d = 4) with tsvd! truncation to D: time split eigsolve / tsvd and the
+    Jacobi sweep counts on the theta tensors a real run produces (graded Schmidt spectra)."""
+    H = mk.hubbard(1.0, 4.0, be=be)
+    psi = mk.FiniteMPS.random(L, 4, D, np.random.default_rng(3), be=be)
+    stat = {"svd_s": 0.0, "svd_n": 0, "sweeps": [], "eig_s": 0.0}
+    orig_tsvd, orig_fp = be.tsvd, alg.fixedpoint
+
+    def tsvd_timed(*a, **k):
+        sync(); t0 = time.perf_counter()
+        out = orig_tsvd(*a, **k)
+        sync(); stat["svd_s"] += time.perf_counter() - t0; stat["svd_n"] += 1
+        stat["sweeps"].append(be.svd_sweeps())
+        return out
+
+    def fp_timed(*a, **k):
+        sync(); t0 = time.perf_counter()
+        out = orig_fp(*a, **k)
+        sync(); stat["eig_s"] += time.perf_counter() - t0
+        return out
+
+    be.tsvd, alg.fixedpoint = tsvd_timed, fp_timed
+    try:
+        for it in range(2):
+            for k in stat:
+                stat[k] = [] if k == "sweeps" else 0
+            q0 = be.qr_stats()
+            sync(); t0 = time.perf_counter()
+            psi, envs, eps = mk.find_groundstate(psi, H, mk.DMRG2(tol=1e-14, maxiter=1, trunc_dim=D,
+                                                                  eigalg=mk.Arnoldi(fixed_matvecs=8, krylovdim=8)))
+            sync(); dt = time.perf_counter() - t0
+            q1 = be.qr_stats()
+            sw = stat["sweeps"]
+            print(f"c4sweep Hubbard L={L} D={D} sweep {it + 1}: {dt:.2f} s  eigsolve {stat['eig_s']:.2f} s  tsvd {stat['svd_s']:.2f} s "
+                  f"({stat['svd_n']} calls, Jacobi sweeps min/mean/max {min(sw)}/{np.mean(sw):.1f}/{max(sw)}), "
+                  f"qr +{ {k: q1[k] - q0[k] for k in q1} }, max bond {max(psi.bond_dims())}", flush=True)
+    finally:
+        be.tsvd, alg.fixedpoint = orig_tsvd, orig_fp
+
+
 def tsvd(be):
     for n in (512, 1024, 2048, 4096):
         A = mk.DTensor(torch.rand(n * n, dtype=torch.float64, device=be.device), (n, n))
