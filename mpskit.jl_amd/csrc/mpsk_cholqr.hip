@@ -1,13 +1,15 @@
 // Fast path of QRpos: shifted CholeskyQR3 on the MFMA GEMM core.
 //
-//   pass(X):  G = X^T X  (+ shift on the first pass)  ->  G = R^T R (blocked Cholesky, 64-wide)
-//             -> R^{-1} (64x64 inverses in LDS + recursive doubling with batched GEMMs)
+//   pass(X):  G = X^T X  (+ shift on the first pass)  ->  G = R^T R : blocked right-looking Cholesky, ONE fused
+//             launch per 64-column block (cq_step_kernel: trailing update through the 64x64 inverse, Cholesky of
+//             the next diagonal block and its inverse in MFMA accumulators, out-of-place panel solve)
+//             -> R^{-1} (diagonal-block inverses come out of the step kernel; recursive doubling with batched GEMMs)
 //             -> Q = X R^{-1}
 //   A --pass(shifted)--> Q1,R1 --pass--> Q2,R2 --pass--> Q3,R3 ;  Q = Q3, R = R3 R2 R1.
 //
 // Every flop-heavy step is a GEMM (Gram, trailing Cholesky update, inverse doubling, Q = X R^-1),
-// so a (2048 x 1024) QR costs ~1 ms instead of the ~17 ms of the LDS-panel Householder kernel
-// (profiles/r01_*).  Cholesky yields diag(R) > 0 directly, which is the QRpos convention
+// so a (2048 x 1024) QR costs ~2 ms instead of the ~25 ms of the LDS-panel Householder kernel
+// (profiles/r01_*); the latency-bound Cholesky chain (32 launches x ~29 us) is about half of that.  Cholesky yields diag(R) > 0 directly, which is the QRpos convention
 // (TensorKit leftorth!(; alg = QRpos())); for a full-column-rank matrix the factorisation is unique,
 // so this agrees with Householder QRpos to O(cond * eps).
 // Robustness: the first pass is shifted (Fukaya et al., "Shifted Cholesky QR", SIAM J. Sci. Comput.
@@ -58,45 +60,185 @@ __device__ __forceinline__ double cq_readlane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// Cholesky (upper, G_kk = R^T R) of one 64x64 diagonal block on the MATRIX CORES: the block lives
-// in MFMA accumulators (4 waves x 2x2 tiles of 16x16); rows are eliminated four at a time:
-//   (a) the owners copy rows j0..j0+3 to LDS,  (b) wave 0 factors that 4 x 64 panel with
-//   cross-lane reads (lane = column),  (c) every wave applies the rank-4 update
-//   acc -= P^T P with v_mfma_f64_16x16x4_f64 (K = 4 is exactly the MFMA depth).
-// 16 chunks x 2 barriers instead of 64 latency-bound column steps (profiles/r01: 79 us -> ~10 us).
-// Writes R_kk over G_kk (strict lower part zeroed).
-__global__ __launch_bounds__(256) void cq_potrf64_mfma_kernel(double* __restrict__ G, int npad, int k,
-                                                              int* __restrict__ flag) {
-  __shared__ double P[2][4][CB];
+// ---- fused right-looking Cholesky step --------------------------------------------------------------
+// One launch per 64-column block k (instead of potrf + trsm + syrk = three dependent launches):
+//   * trailing tiles (i, j), k <= i <= j:  G_ij -= Y_i^T Y_j with Y_x = R_{k-1,k-1}^-T G_{k-1,x} formed in the tile
+//     from the 64x64 triangular inverse -- the panel solve is folded into the update, the tiles only need the
+//     UNSOLVED row block k-1 of G and there is no separate triangular solve on the critical path;
+//   * the workgroup that owns tile (k, k) keeps the updated tile in its MFMA accumulators and factors it on
+//     the spot: Cholesky of [G_kk | I] by 4-row chunks with rank-4 MFMA updates gives R_kk AND R_kk^-T
+//     (Gaussian elimination of the augmented block) for the next launch;
+//   * panel tiles j >= k:  R_{k-1,j} = R_{k-1,k-1}^-T G_{k-1,j}  (out of place, G's row block stays intact
+//     for the trailing tiles of the same launch).
+// R (out) and the Rinv diagonal blocks (out) are written; G is consumed.  LDS tiles hold element (r, c) at c * CQ_SL + r.
+constexpr int CQ_SL = 66;
+constexpr size_t CQ_STEP_LDS = (size_t)3 * CB * CQ_SL * sizeof(double);
+
+typedef double cq_d2 __attribute__((ext_vector_type(2)));
+// 64 x 64 tile (ld npad) -> registers (all 8 loads in flight) -> LDS
+__device__ __forceinline__ void cq_fetch_tile(cq_d2 (&r)[8], const double* __restrict__ src, int npad, int tid) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int v = tid + 256 * q, r2 = (v & 31) * 2, c = v >> 5;
+    r[q] = *reinterpret_cast<const cq_d2*>(&src[r2 + (int64_t)c * npad]);
+  }
+}
+__device__ __forceinline__ void cq_put_tile(double* __restrict__ dst, const cq_d2 (&r)[8], int tid) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int v = tid + 256 * q, r2 = (v & 31) * 2, c = v >> 5;
+    *reinterpret_cast<cq_d2*>(&dst[c * CQ_SL + r2]) = r[q];
+  }
+}
+
+// acc[ti][tj] (+)= sign * (tA^T tB) sub-tile of this wave:  D(r, c) = sum_l tA(l, r) tB(l, c)
+__device__ __forceinline__ void cq_prod(cq_d4 (&acc)[2][2], const double* __restrict__ tA, const double* __restrict__ tB,
+                                        double sign, int wr, int wc, int fr, int fq) {
+  for (int l0 = 0; l0 < CB; l0 += 4) {
+    double af[2], bf[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) af[ti] = sign * tA[(32 * wr + 16 * ti + fr) * CQ_SL + l0 + fq];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) bf[tj] = tB[(32 * wc + 16 * tj + fr) * CQ_SL + l0 + fq];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, double* __restrict__ R,
+                                                      double* __restrict__ Rinv, int npad, int k,
+                                                      int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) double cq_sm[];
+  double* sM = cq_sm;                      // R_{k-1,k-1}^-1
+  double* sJ = cq_sm + CB * CQ_SL;         // G_{k-1, j}
+  double* sI = cq_sm + 2 * CB * CQ_SL;     // G_{k-1, i}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, lr = lane >> 4, lc = lane & 15;
-  double* Gk = G + (int64_t)k * CB * (npad + 1);
+  const int wr = wave >> 1, wc = wave & 1, fq = lane >> 4, fr = lane & 15;
+  const int nb = npad / CB, kk = k - 1, nt = nb - k;
+  const int ntrail = (k == 0) ? 1 : nt * (nt + 1) / 2;
+  const int b = blockIdx.x;
   cq_d4 acc[2][2];
+  if (b >= ntrail) {                       // ---- panel tile: R_{kk, j} = Rinv_kk^T G_{kk, j}
+    const int j = k + (b - ntrail);
+    cq_d2 t0[8], t1[8];
+    cq_fetch_tile(t0, Rinv + (int64_t)kk * CB * (npad + 1), npad, tid);
+    cq_fetch_tile(t1, G + (int64_t)kk * CB + (int64_t)j * CB * npad, npad, tid);
+    cq_put_tile(sM, t0, tid);
+    cq_put_tile(sJ, t1, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0};
+    cq_prod(acc, sM, sJ, 1.0, wr, wc, fr, fq);
+    double* Rb = R + (int64_t)kk * CB + (int64_t)j * CB * npad;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          Rb[(32 * wr + 16 * ti + fq + 4 * rg) + (int64_t)(32 * wc + 16 * tj + fr) * npad] = acc[ti][tj][rg];
+    return;
+  }
+  int i = k, j = k;
+  if (k > 0) {
+    int ii = 0, rem = b;
+    while (rem >= nt - ii) { rem -= nt - ii; ++ii; }
+    i = k + ii; j = i + rem;
+  }
+  double* Gij = G + (int64_t)i * CB + (int64_t)j * CB * npad;
+  cq_d2 t0[8], t1[8], t2[8];
+  if (k > 0) {                              // all operand loads in flight before anything is consumed
+    cq_fetch_tile(t0, Rinv + (int64_t)kk * CB * (npad + 1), npad, tid);                 // R_{kk,kk}^-1
+    cq_fetch_tile(t1, G + (int64_t)kk * CB + (int64_t)j * CB * npad, npad, tid);
+    cq_fetch_tile(t2, G + (int64_t)kk * CB + (int64_t)i * CB * npad, npad, tid);
+  }
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
-        acc[ti][tj][rg] = Gk[(32 * wr + 16 * ti + lr + 4 * rg) + (int64_t)(32 * wc + 16 * tj + lc) * npad];
+        acc[ti][tj][rg] = Gij[(32 * wr + 16 * ti + fq + 4 * rg) + (int64_t)(32 * wc + 16 * tj + fr) * npad];
+  if (k > 0) {
+    cq_put_tile(sM, t0, tid);
+    cq_put_tile(sJ, t1, tid);
+    cq_put_tile(sI, t2, tid);
+    __syncthreads();
+    // Y_j = R_kk^-T G_{kk,j} and Y_i = R_kk^-T G_{kk,i} (the solved panels, recomputed per tile: 2 x 64^3 MFMA
+    // flops), then G_ij -= Y_i^T Y_j.  Going through the triangular inverse keeps the error at cond(R_kk) u;
+    // the shorter form G_kk^-1 = R^-1 R^-T squares the condition number and broke shifted Cholesky on graded input.
+    cq_d4 yj[2][2], yi[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) { yj[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0}; yi[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0}; }
+    cq_prod(yj, sM, sJ, 1.0, wr, wc, fr, fq);
+    cq_prod(yi, sM, sI, 1.0, wr, wc, fr, fq);
+    __syncthreads();                                        // everyone is done reading the unsolved panels
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int o = (32 * wc + 16 * tj + fr) * CQ_SL + 32 * wr + 16 * ti + fq + 4 * rg;
+          sJ[o] = yj[ti][tj][rg];
+          sI[o] = yi[ti][tj][rg];
+        }
+    __syncthreads();
+    cq_prod(acc, sI, sJ, -1.0, wr, wc, fr, fq);             // G_ij -= Y_i^T Y_j
+  }
+  if (b != 0) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          Gij[(32 * wr + 16 * ti + fq + 4 * rg) + (int64_t)(32 * wc + 16 * tj + fr) * npad] = acc[ti][tj][rg];
+    return;
+  }
+  // ---- tile (k, k): Cholesky of [G_kk | I] in the accumulators -> R_kk, R_kk^-T, then M_k
+  __syncthreads();                                          // LDS is reused below
+  double (*P)[4][2 * CB] = reinterpret_cast<double (*)[4][2 * CB]>(cq_sm);       // P[2][4][128]
+  cq_d4 accE[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        accE[ti][tj][rg] = ((32 * wr + 16 * ti + fq + 4 * rg) == (32 * wc + 16 * tj + fr)) ? 1.0 : 0.0;
+  double* Rk = R + (int64_t)k * CB * (npad + 1);
+  double* Xk = Rinv + (int64_t)k * CB * (npad + 1);
   int bad = 0;
-  for (int c = 0; c < CB / 4; ++c) {
+  // chunk c = 8 rb + 4 ti + q with (ti, q) compile-time: the accumulator registers are indexed statically
+  // (a runtime (ti, q) made the compiler spill both accumulator sets to scratch every chunk)
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 8 * rb + 4 * ti + q;
     const int j0 = 4 * c;
-    double (*Pb)[CB] = P[c & 1];
-    if (wr == (j0 >> 5)) {                 // (a) rows j0 + lr live in tile row ti, register q
-      const int ti = (j0 >> 4) & 1, q = (j0 >> 2) & 3;
+    double (*Pb)[2 * CB] = P[c & 1];
+    if (wr == rb) {                        // rows j0 + fq live in tile row ti, register q of wave row rb
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
-        const cq_d4 v = ti ? acc[1][tj] : acc[0][tj];
-        const double e = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
-        Pb[lr][32 * wc + 16 * tj + lc] = e;
+        Pb[fq][32 * wc + 16 * tj + fr] = acc[ti][tj][q];
+        Pb[fq][CB + 32 * wc + 16 * tj + fr] = accE[ti][tj][q];
       }
     }
     __syncthreads();
-    if (wave == 0) {                       // (b) 4 x 64 panel, lane = column
-      double p[4];
+    if (wave == 0) {                       // 4 x (64 | 64) panel, lane = column of both halves
+      double p[4], e[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) p[t] = Pb[t][lane];
+      for (int t = 0; t < 4; ++t) { p[t] = Pb[t][lane]; e[t] = Pb[t][CB + lane]; }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const double piv = cq_readlane(p[t], j0 + t);
@@ -105,105 +247,37 @@ __global__ __launch_bounds__(256) void cq_potrf64_mfma_kernel(double* __restrict
         const double sq = ok ? sqrt(piv) : 1.0;
         const double rs = ok ? 1.0 / sq : 0.0;
         p[t] = (lane > j0 + t) ? p[t] * rs : (lane == j0 + t ? sq : 0.0);
+        e[t] *= rs;
 #pragma unroll
         for (int u = t + 1; u < 4; ++u) {
           const double r = cq_readlane(p[t], j0 + u);
           p[u] -= r * p[t];
+          e[u] -= r * e[t];
         }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         Pb[t][lane] = p[t];
-        Gk[(j0 + t) + (int64_t)lane * npad] = p[t];
+        Pb[t][CB + lane] = e[t];
+        Rk[(j0 + t) + (int64_t)lane * npad] = p[t];          // R_kk(j0+t, lane)
+        Xk[lane + (int64_t)(j0 + t) * npad] = e[t];          // R_kk^-1(lane, j0+t) = E(j0+t, lane)
       }
     }
     __syncthreads();
-    double af[2], bf[2];                   // (c) rank-4 update on the matrix cores
+    double af[2], bf[2], be[2];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) af[ti] = -Pb[lr][32 * wr + 16 * ti + lc];
+    for (int t2 = 0; t2 < 2; ++t2) af[t2] = -Pb[fq][32 * wr + 16 * t2 + fr];
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) bf[tj] = Pb[lr][32 * wc + 16 * tj + lc];
+    for (int tj = 0; tj < 2; ++tj) { bf[tj] = Pb[fq][32 * wc + 16 * tj + fr]; be[tj] = Pb[fq][CB + 32 * wc + 16 * tj + fr]; }
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+      for (int tj = 0; tj < 2; ++tj) {
+        acc[t2][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t2], bf[tj], acc[t2][tj], 0, 0, 0);
+        accE[t2][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t2], be[tj], accE[t2][tj], 0, 0, 0);
+      }
   }
   if (wave == 0 && lane == 0 && bad) atomicOr(flag, 1);
-}
-
-// panel (64 x rest, ld npad)  <-  R_kk^{-T} panel : forward substitution, one thread per column with the
-// column in registers and R_kk broadcast from LDS (fully unrolled: 2016 FMAs per thread).
-__global__ __launch_bounds__(256) void cq_trsm_panel_kernel(const double* __restrict__ Rkk, double* __restrict__ panel,
-                                                            int npad, int rest) {
-  __shared__ double Rc[CB][CB];            // Rc[i][l] = R[l][i]  (column i contiguous in l)
-  __shared__ double dinv[CB];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < CB * CB; e += 256) {
-    const int l = e & 63, i = e >> 6;
-    Rc[i][l] = Rkk[l + (int64_t)i * npad];
-  }
-  if (tid < CB) dinv[tid] = 1.0 / Rkk[tid + (int64_t)tid * npad];
-  __syncthreads();
-  const int col = blockIdx.x * 256 + tid;
-  if (col >= rest) return;
-  double* pc = panel + (int64_t)col * npad;
-  double x[CB];
-#pragma unroll
-  for (int i = 0; i < CB; ++i) x[i] = pc[i];
-#pragma unroll
-  for (int i = 0; i < CB; ++i) {
-    double s = x[i];
-#pragma unroll
-    for (int l = 0; l < i; ++l) s -= Rc[i][l] * x[l];
-    x[i] = s * dinv[i];
-  }
-#pragma unroll
-  for (int i = 0; i < CB; ++i) pc[i] = x[i];
-}
-
-// Rinv diagonal blocks (all at once, off the critical path): inverse of each upper-triangular R_bb.
-// Thread (i0 = tid >> 6, c = tid & 63) keeps rows i0 + 4k of column c of the inverse in registers;
-// step i reads row i only (x_i = Y[i][c] / R[i][i]) and updates the rows above it.
-__global__ __launch_bounds__(256) void cq_diag_inverse_kernel(const double* __restrict__ R, double* __restrict__ Rinv,
-                                                              int npad) {
-  __shared__ double S[CB][CB + 1];
-  __shared__ double rowbuf[2][CB];
-  __shared__ double dinvd[CB];
-  const int tid = threadIdx.x, c = tid & 63, i0 = tid >> 6;
-  const double* Rb = R + (int64_t)blockIdx.x * CB * (npad + 1);
-  double* Xb = Rinv + (int64_t)blockIdx.x * CB * (npad + 1);
-  for (int e = tid; e < CB * CB; e += 256) S[e & 63][e >> 6] = Rb[(e & 63) + (int64_t)(e >> 6) * npad];
-  __syncthreads();
-  if (tid < CB) dinvd[tid] = 1.0 / S[tid][tid];
-  double x[CB / 4];
-#pragma unroll
-  for (int kk = 0; kk < CB / 4; ++kk) x[kk] = ((i0 + 4 * kk) == c) ? 1.0 : 0.0;
-  __syncthreads();
-  for (int i = CB - 1; i >= 0; --i) {
-    if (i0 == (i & 3)) {
-      double v = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < CB / 4; ++kk) if (kk == (i >> 2)) v = x[kk];
-      rowbuf[i & 1][c] = v;
-    }
-    __syncthreads();
-    const double xi = rowbuf[i & 1][c] * dinvd[i];
-    double sv[CB / 4];
-#pragma unroll
-    for (int kk = 0; kk < CB / 4; ++kk) sv[kk] = S[i0 + 4 * kk][i];
-#pragma unroll
-    for (int kk = 0; kk < CB / 4; ++kk) {
-      const int r = i0 + 4 * kk;
-      const double upd = sv[kk] * xi;
-      x[kk] -= (r < i && c >= i) ? upd : 0.0;
-    }
-  }
-#pragma unroll
-  for (int kk = 0; kk < CB / 4; ++kk) {
-    const int r = i0 + 4 * kk;
-    Xb[r + (int64_t)c * npad] = (r <= c) ? x[kk] * dinvd[r] : 0.0;
-  }
 }
 
 // zero everything outside the block upper triangle of R (garbage of the trailing updates) and
@@ -250,30 +324,28 @@ static GemmArgs cq_mk(const double* A, const double* B, double* C, int M, int N,
 static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, double* Q, int ldq, double* Rp,
                           double* Rinv, double* T, bool shifted, bool check_identity, int* flag, hipStream_t s) {
   hipError_t e;
-  GemmArgs g = cq_mk(X, X, Rp, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X
+  double* Gw = T;                                                            // Gram matrix, consumed by the factorization
+  GemmArgs g = cq_mk(X, X, Gw, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X
   if ((e = gemm_f64(g, s)) != hipSuccess) return e;
-  if (npad > n) hipLaunchKernelGGL(cq_pad_identity_kernel, dim3(512), dim3(256), 0, s, Rp, npad, n);
-  if (check_identity) hipLaunchKernelGGL(cq_check_identity_kernel, dim3(256), dim3(256), 0, s, Rp, npad, n, 0.5, flag);
+  if (npad > n) hipLaunchKernelGGL(cq_pad_identity_kernel, dim3(512), dim3(256), 0, s, Gw, npad, n);
+  if (check_identity) hipLaunchKernelGGL(cq_check_identity_kernel, dim3(256), dim3(256), 0, s, Gw, npad, n, 0.5, flag);
   if (shifted) {
     const double u = 1.1102230246251565e-16;
     const double factor = 11.0 * ((double)m * n + (double)n * (n + 1)) * u;
-    hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, s, Rp, npad, n, factor);
+    hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, s, Gw, npad, n, factor);
   }
   const int nb = npad / CB;
-  for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(cq_potrf64_mfma_kernel, dim3(1), dim3(256), 0, s, Rp, npad, k, flag);
-    const int rest = npad - (k + 1) * CB;
-    if (rest <= 0) break;
-    double* panel = Rp + (int64_t)k * CB + (int64_t)(k + 1) * CB * npad;     // rows k-block, cols > k-block
-    const double* Rkk = Rp + (int64_t)k * CB * (npad + 1);
-    // panel <- R_kk^{-T} panel
-    hipLaunchKernelGGL(cq_trsm_panel_kernel, dim3((rest + 255) / 256), dim3(256), 0, s, Rkk, panel, npad, rest);
-    // trailing -= panel^T panel
-    double* trail = Rp + (int64_t)(k + 1) * CB * (npad + 1);
-    g = cq_mk(panel, panel, trail, rest, rest, CB, npad, npad, npad, 1, -1.0, 1.0);
-    if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+  static bool step_attr = false;
+  if (!step_attr) {
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cq_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)CQ_STEP_LDS)) != hipSuccess) return e;
+    step_attr = true;
   }
-  hipLaunchKernelGGL(cq_diag_inverse_kernel, dim3(nb), dim3(256), 0, s, Rp, Rinv, npad);
+  for (int k = 0; k < nb; ++k) {            // one fused launch per block column (see cq_step_kernel)
+    const int nt = nb - k;
+    const int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt;
+    hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag);
+  }
   hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
   // R^{-1} by recursive doubling: inv([R11 R12; 0 R22]) = [i11, -i11 R12 i22; 0, i22]
   for (int b = CB; b < npad; b <<= 1) {

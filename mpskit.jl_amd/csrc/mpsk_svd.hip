@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
   // three dot products with two shuffles and rotate their 8 rows of R and W.  (The earlier two-sided
   // LDS version cost ~2.5 us per step = 315 us per call, 85 % of the SVD; profiles/r01_other_configs.)
   {
-    // (1) Cholesky, rows four at a time, rank-4 MFMA updates (same scheme as cq_potrf64_mfma_kernel)
+    // (1) Cholesky, rows four at a time, rank-4 MFMA updates (same scheme as cq_step_kernel in mpsk_cholqr.hip)
     __shared__ double P[2][4][J2];
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, lr = lane >> 4, lc = lane & 15;
