@@ -52,10 +52,13 @@ int mpsk_ctx_destroy(mpsk_ctx* ctx);
 int mpsk_ctx_set_stream(mpsk_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = default */
 int mpsk_ctx_synchronize(mpsk_ctx* ctx);
 int mpsk_ctx_workspace_reserve(mpsk_ctx* ctx, size_t bytes);   /* pre-size the private workspace */
-/* QRpos algorithm: 0 auto (shifted CholeskyQR3 on the GEMM core, Householder fallback when the device
- * flags an ill-conditioned / rank-deficient input), 1 Householder only, 2 CholeskyQR3 only (error on flag) */
+/* QRpos algorithm: 0 auto (shifted CholeskyQR3 on the GEMM core; when the device flags an ill-conditioned /
+ * rank-deficient input: perturbed, repeatedly shifted CholeskyQR, then blocked Householder as the last resort),
+ * 1 Householder only, 2 CholeskyQR3 only (error on flag).
+ * Counters: factorizations finished by CholeskyQR3 / by Householder / CholeskyQR3 attempts that were flagged /
+ * flagged inputs finished by the robust CholeskyQR variant (any pointer may be NULL). */
 int mpsk_ctx_set_qr_mode(mpsk_ctx* ctx, int mode);
-int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallback);
+int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallback, long* n_robust);
 /* tsvd algorithm switch: precondition = 1 (default) factors the tall orientation of theta with QRpos first and
  * runs the block-Jacobi iteration on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra),
  * 0 = Jacobi on theta directly.  mpsk_ctx_svd_stats returns the number of Jacobi sweeps of the last mpsk_tsvd. */

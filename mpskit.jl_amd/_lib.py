@@ -33,7 +33,7 @@ SIGNATURES = {
     "mpsk_ctx_workspace_reserve": [C.c_void_p, C.c_size_t],
     "mpsk_ctx_force_tile": [C.c_void_p, C.c_int, C.c_int],
     "mpsk_ctx_set_qr_mode": [C.c_void_p, C.c_int],
-    "mpsk_ctx_qr_stats": [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)],
+    "mpsk_ctx_qr_stats": [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "mpsk_ctx_set_svd_mode": [C.c_void_p, C.c_int],
     "mpsk_ctx_svd_stats": [C.c_void_p, C.POINTER(C.c_int)],
     "mpsk_prof_enable": [C.c_void_p, C.c_int],

@@ -79,9 +79,9 @@ class Backend:
         check(self.lib.mpsk_ctx_set_qr_mode(self.ctx, int(mode)), "mpsk_ctx_set_qr_mode")
 
     def qr_stats(self):
-        a, b, f = C.c_long(), C.c_long(), C.c_long()
-        check(self.lib.mpsk_ctx_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(f)), "mpsk_ctx_qr_stats")
-        return {"cholqr3": a.value, "householder": b.value, "fallback": f.value}
+        a, b, f, r = C.c_long(), C.c_long(), C.c_long(), C.c_long()
+        check(self.lib.mpsk_ctx_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(f), C.byref(r)), "mpsk_ctx_qr_stats")
+        return {"cholqr3": a.value, "householder": b.value, "fallback": f.value, "robust": r.value}
 
     def set_svd_mode(self, precondition=True):
         check(self.lib.mpsk_ctx_set_svd_mode(self.ctx, int(bool(precondition))), "mpsk_ctx_set_svd_mode")

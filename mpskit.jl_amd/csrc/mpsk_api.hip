@@ -47,7 +47,7 @@ struct mpsk_ctx {
   int svd_precondition = 1;     // QR-preconditioned Jacobi (mpsk_ctx_set_svd_mode)
   int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
   int* d_flag = nullptr;
-  long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0;
+  long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0, n_qr_robust = 0;
   // second stream + workspace for two concurrent factorizations (mpsk_qrpos2)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -484,8 +484,9 @@ int mpsk_regularize(mpsk_ctx* c, int W, int D1, int D2, void* v, const void* lve
   return MPSK_OK;
 }
 
-// QRpos dispatcher: CholeskyQR3 (GEMM-rich) for n > 64 with a Householder fallback when the device
-// flag reports a non-positive pivot / a Gram matrix far from the identity (rank-deficient input).
+// QRpos dispatcher: CholeskyQR3 (GEMM-rich) for n > 64; when the device flag reports a non-positive pivot / a
+// Gram matrix far from the identity (ill-conditioned or rank-deficient input) the perturbed, repeatedly shifted
+// variant (cholqr_robust) runs, and only if that fails too the blocked Householder kernel.
 static int qrpos_dispatch(mpsk_ctx* c, int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr,
                           double* ws) {
   std::string err;
@@ -496,6 +497,10 @@ static int qrpos_dispatch(mpsk_ctx* c, int m, int n, const double* A, int lda, d
     if (flag == 0) { c->n_qr_chol++; return MPSK_OK; }
     if (c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
     c->n_qr_fallback++;
+    // second line of defence, still on the GEMM core: perturbed, repeatedly shifted CholeskyQR
+    e = cholqr_robust(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream);
+    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr_robust: ") + hipGetErrorString(e));
+    if (flag == 0) { c->n_qr_robust++; return MPSK_OK; }
   }
   c->n_qr_house++;
   hipError_t e = qrpos(m, n, A, lda, Q, ldq, R, ldr, ws, c->stream, &err);
@@ -514,11 +519,12 @@ int mpsk_ctx_set_qr_mode(mpsk_ctx* c, int mode) {
   c->qr_mode = mode;
   return MPSK_OK;
 }
-int mpsk_ctx_qr_stats(mpsk_ctx* c, long* n_chol, long* n_house, long* n_fallback) {
+int mpsk_ctx_qr_stats(mpsk_ctx* c, long* n_chol, long* n_house, long* n_fallback, long* n_robust) {
   REQUIRE(c, "ctx is NULL");
   if (n_chol) *n_chol = c->n_qr_chol;
   if (n_house) *n_house = c->n_qr_house;
   if (n_fallback) *n_fallback = c->n_qr_fallback;
+  if (n_robust) *n_robust = c->n_qr_robust;
   return MPSK_OK;
 }
 
@@ -576,15 +582,19 @@ int mpsk_qrpos2(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1, i
   if (f2 == 0) c->n_qr_chol++;
   if ((f1 != 0 || f2 != 0) && c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
   std::string err;
-  if (f1 != 0) {
-    c->n_qr_fallback++; c->n_qr_house++;
-    hipError_t e2 = qrpos(m, n, (const double*)A1, lda1, (double*)Q1, ldq1, (double*)R1, ldr1, (double*)c->ws, c->stream, &err);
-    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (1) failed");
-  }
-  if (f2 != 0) {
-    c->n_qr_fallback++; c->n_qr_house++;
-    hipError_t e2 = qrpos(m, n, (const double*)A2, lda2, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws, c->stream, &err);
-    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (2) failed");
+  const void* As[2] = {A1, A2}; void* Qs[2] = {Q1, Q2}; void* Rs[2] = {R1, R2};
+  const int ldas[2] = {lda1, lda2}, ldqs[2] = {ldq1, ldq2}, ldrs[2] = {ldr1, ldr2}, fl[2] = {f1, f2};
+  for (int t = 0; t < 2; ++t) {
+    if (fl[t] == 0) continue;
+    c->n_qr_fallback++;
+    int flag = 0;
+    hipError_t e2 = cholqr_robust(m, n, (const double*)As[t], ldas[t], (double*)Qs[t], ldqs[t], (double*)Rs[t], ldrs[t],
+                                  (double*)c->ws, c->d_flag, &flag, c->stream);
+    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "cholqr_robust (pair) failed");
+    if (flag == 0) { c->n_qr_robust++; continue; }
+    c->n_qr_house++;
+    e2 = qrpos(m, n, (const double*)As[t], ldas[t], (double*)Qs[t], ldqs[t], (double*)Rs[t], ldrs[t], (double*)c->ws, c->stream, &err);
+    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (pair) failed");
   }
   return MPSK_OK;
 }

@@ -459,6 +459,80 @@ hipError_t cholqr3_finalize(int m, int n, double* Q, int ldq, double* R, int ldr
   return hipGetLastError();
 }
 
+// ---- robust variant for ill-conditioned / rank-deficient input (what used to go to Householder) ------------
+// X = A + delta N with N = +-1 pseudo-random and delta = u ||A||_F / sqrt(m): a backward error at rounding level
+// that gives exactly dependent columns a direction of their own (sigma_min ~ u ||A||), so cond(X) <~ 1e16.
+// Each SHIFTED pass divides the condition number by ~1e4..1e5 (sigma -> sigma / sqrt(sigma^2 + s)), so three
+// shifted passes + one plain pass + the first-order pass reach orthogonality 1e-15:  R = R5 R4 R3 R2 R1.
+__global__ __launch_bounds__(256) void cq_sumsq_kernel(const double* __restrict__ A, int lda, int m, int n,
+                                                       double* __restrict__ out) {
+  __shared__ double red[4];
+  const int64_t total = (int64_t)m * n;
+  double acc = 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const double v = A[(e % m) + (e / m) * (int64_t)lda];
+    acc += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void cq_perturb_kernel(const double* __restrict__ A, int lda, int m, int n,
+                                                         double* __restrict__ X, int ldx, const double* __restrict__ sumsq) {
+  const double delta = 1.1102230246251565e-16 * sqrt(sumsq[0] / (double)m);
+  const int64_t total = (int64_t)m * n;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned r = (unsigned)(e % m), c = (unsigned)(e / m);
+    unsigned h = (r * 0x9E3779B1u) ^ (c * 0x85EBCA77u);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    X[r + (int64_t)c * ldx] = A[r + (int64_t)c * lda] + ((h & 1u) ? delta : -delta);
+  }
+}
+
+hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
+                         int* d_flag, int* flag_out, hipStream_t s) {
+  const CqBufs b = cq_bufs(m, n, ws);
+  const int npad = b.npad;
+  hipError_t e;
+  double* sumsq = b.T;                       // T is free until the first pass
+  if ((e = hipMemsetAsync(sumsq, 0, sizeof(double), s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(cq_sumsq_kernel, dim3(512), dim3(256), 0, s, A, lda, m, n, sumsq);
+  hipLaunchKernelGGL(cq_perturb_kernel, dim3(1024), dim3(256), 0, s, A, lda, m, n, b.Qa, m, sumsq);
+  double *acc = b.R1, *cur = b.R2, *tmp = b.R3;
+  double *X = b.Qa, *Y = b.Qb;
+  auto accumulate = [&]() -> hipError_t {    // acc <- cur * acc
+    GemmArgs g = cq_mk(cur, acc, tmp, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
+    hipError_t ee = gemm_f64(g, s);
+    double* t = acc; acc = tmp; tmp = t;
+    return ee;
+  };
+  for (int p = 0; p < 4; ++p) {
+    double* Rp = (p == 0) ? acc : cur;
+    if ((e = cq_pass(m, n, npad, X, m, Y, m, Rp, b.Rinv, b.T, /*shifted=*/p < 3, false, d_flag, s)) != hipSuccess) return e;
+    if (p > 0 && (e = accumulate()) != hipSuccess) return e;
+    double* t = X; X = Y; Y = t;
+  }
+  if ((e = cq_pass_firstorder(m, n, npad, X, m, Q, ldq, cur, b.Rinv, b.T, d_flag, s)) != hipSuccess) return e;
+  if ((e = accumulate()) != hipSuccess) return e;
+  hipLaunchKernelGGL(cq_copy_upper_kernel, dim3(1024), dim3(256), 0, s, acc, npad, n, R, ldr);
+  if ((e = hipMemcpyAsync(flag_out, d_flag, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+  if (*flag_out == 4) {                      // the plain pass left more than 1e-7: one more full pass (undo the last product)
+    { double* t = acc; acc = tmp; tmp = t; }
+    if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
+    if ((e = cq_pass(m, n, npad, X, m, Y, m, cur, b.Rinv, b.T, false, false, d_flag, s)) != hipSuccess) return e;
+    if ((e = accumulate()) != hipSuccess) return e;
+    if ((e = cq_pass_firstorder(m, n, npad, Y, m, Q, ldq, cur, b.Rinv, b.T, d_flag, s)) != hipSuccess) return e;
+    if ((e = accumulate()) != hipSuccess) return e;
+    hipLaunchKernelGGL(cq_copy_upper_kernel, dim3(1024), dim3(256), 0, s, acc, npad, n, R, ldr);
+    if ((e = hipMemcpyAsync(flag_out, d_flag, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+  }
+  return hipGetLastError();
+}
+
 hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                    int* d_flag, int* flag_out, hipStream_t s) {
   hipError_t e = cholqr3_enqueue(m, n, A, lda, Q, ldq, R, ldr, ws, d_flag, flag_out, s);

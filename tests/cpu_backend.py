@@ -42,7 +42,7 @@ class CpuBackend:
 
     def __init__(self):
         self.calls = {}
-        self._qr = {"cholqr3": 0, "householder": 0, "fallback": 0}
+        self._qr = {"cholqr3": 0, "householder": 0, "fallback": 0, "robust": 0}
 
     def _count(self, name):
         self.calls[name] = self.calls.get(name, 0) + 1

@@ -174,11 +174,15 @@ def test_qrpos_fallback_counts(be):
     s0 = be.qr_stats()
     be.qrpos(be.upload(rng.random((512, 256))))            # well conditioned -> CholeskyQR3
     A = rng.random((512, 256))
-    A[:, 7] = 0.0                                            # rank deficient -> Householder fallback
-    be.qrpos(be.upload(A))
+    A[:, 7] = 0.0                                            # rank deficient -> flagged, finished by the robust variant
+    Q, R = be.qrpos(be.upload(A))
     s1 = be.qr_stats()
     assert s1["cholqr3"] == s0["cholqr3"] + 1
-    assert s1["fallback"] == s0["fallback"] + 1 and s1["householder"] == s0["householder"] + 1
+    assert s1["fallback"] == s0["fallback"] + 1
+    assert (s1["robust"] - s0["robust"]) + (s1["householder"] - s0["householder"]) == 1
+    Q, R = be.download(Q), be.download(R)
+    assert np.abs(Q.T @ Q - np.eye(256)).max() < 1e-12 and relerr(Q @ R, A) < 1e-13
+    assert np.all(np.diag(R) >= 0) and np.abs(np.tril(R, -1)).max() == 0.0
 
 
 @pytest.mark.parametrize("m,n", [(8, 4), (768, 256), (2048, 1024)])
