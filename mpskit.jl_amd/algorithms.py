@@ -12,7 +12,7 @@ import numpy as np
 
 from .backend import DTensor
 from .derivatives import ddAC, ddAC2, ddC
-from .environments import FinEnv, MPOHamInfEnv, environments
+from .environments import FinEnv, MPOHamInfEnv, MultipleEnvironments, environments
 from .states import FiniteMPS, InfiniteMPS, leftorth, mul_AC
 from . import krylov
 
@@ -104,6 +104,8 @@ def calc_galerkin(psi, pos, envs, h=None):
 def expectation_value(psi, H, envs):
     """Per-site energies (expval.jl:92-109 finite, :111-124 infinite)."""
     be = psi.be
+    if isinstance(envs, MultipleEnvironments):          # expval of a LazySum: sum of the terms' (lazysum.jl)
+        return sum(f * expectation_value(psi, h, e) for f, h, e in zip(H.fs, H, envs.envs))
     if isinstance(psi, FiniteMPS):
         L = len(psi)
         ens = np.zeros(L)
@@ -175,7 +177,7 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None, wrap=None):
 
 def _dmrg(psi, H, alg: DMRG, envs=None):  # dmrg.jl:22-55
     be = psi.be
-    envs = FinEnv(psi, H) if envs is None else envs
+    envs = environments(psi, H) if envs is None else envs
     L = len(psi)
     ws = krylov.KrylovWorkspace(be)
     eps_s = [calc_galerkin(psi, p, envs) for p in range(L)]
@@ -212,7 +214,7 @@ def _two_site_tensor(be, left: DTensor, right: DTensor):
 
 def _dmrg2(psi, H, alg: DMRG2, envs=None):  # dmrg.jl:80-137
     be = psi.be
-    envs = FinEnv(psi, H) if envs is None else envs
+    envs = environments(psi, H) if envs is None else envs
     L = len(psi)
     ws = krylov.KrylovWorkspace(be)
     eps = np.inf
@@ -287,7 +289,7 @@ def _calc_galerkin_inf(psi, envs):
 
 def _vumps(psi, H, alg: VUMPS, envs=None):  # vumps.jl:29-92
     be = psi.be
-    envs = MPOHamInfEnv(psi, H) if envs is None else envs
+    envs = environments(psi, H) if envs is None else envs
     eps = _calc_galerkin_inf(psi, envs)
     n = len(psi)
     ws = krylov.KrylovWorkspace(be)
@@ -417,10 +419,10 @@ def timestep(psi, H, t, dt, alg=None, envs=None):
     """timestep(psi, H, t, dt, alg[, envs]) -> (psi', envs): the copying version (tdvp.jl:148-151)."""
     alg = TDVP() if alg is None else alg
     if isinstance(psi, InfiniteMPS):
-        envs = MPOHamInfEnv(psi, H) if envs is None else envs
+        envs = environments(psi, H) if envs is None else envs
         return _timestep_inf(psi, H, t, dt, alg, envs)
     psi = psi.copy()
-    envs = FinEnv(psi, H) if envs is None else envs
+    envs = environments(psi, H) if envs is None else envs
     if isinstance(alg, TDVP2):
         return _timestep_tdvp2(psi, H, t, dt, alg, envs)
     return _timestep_tdvp(psi, H, t, dt, alg, envs)

@@ -36,16 +36,45 @@ class MPO_ddAC2:  # MPO_∂∂AC2  derivatives.jl:17-22
     __mul__ = __call__
 
 
+class LazyDerivativeSum:  # derivatives.jl:310-323 : (h::LazySum{<:DerivativeOperator})(x) = sum(f_k * h_k(x))
+    def __init__(self, be, terms, fs):
+        self.be, self.terms, self.fs = be, list(terms), list(fs)
+
+    def __call__(self, x: DTensor, out: DTensor = None):
+        y = self.terms[0](x, out=out)
+        if self.fs[0] != 1.0:
+            self.be.scal(self.fs[0], y)
+        for f, h in zip(self.fs[1:], self.terms[1:]):
+            self.be.axpby(f, h(x), 1.0, y)
+        return y
+
+    __mul__ = __call__
+
+
+def _lazy(fn, pos, psi, H, envs):
+    return LazyDerivativeSum(psi.be, [fn(pos, psi, h, e) for h, e in zip(H, envs.envs)], H.fs)
+
+
+def _is_lazy(H, envs):
+    return hasattr(envs, "envs") and hasattr(H, "fs")
+
+
 def ddC(pos, psi, H, envs):  # ∂∂C  derivatives.jl:34-36
+    if _is_lazy(H, envs):
+        return _lazy(ddC, pos, psi, H, envs)
     return MPO_ddC(psi.be, envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi))
 
 
 def ddAC(pos, psi, H, envs):  # ∂∂AC  derivatives.jl:44-46
+    if _is_lazy(H, envs):
+        return _lazy(ddAC, pos, psi, H, envs)
     opp = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
     return MPO_ddAC(psi.be, opp, envs.leftenv(pos, psi), envs.rightenv(pos, psi))
 
 
 def ddAC2(pos, psi, H, envs):  # ∂∂AC2  derivatives.jl:55-58
+    if _is_lazy(H, envs):
+        return _lazy(ddAC2, pos, psi, H, envs)
     o1 = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
     o2 = envs.opp[pos + 1] if hasattr(envs, "opp") else H[pos + 1]
     return MPO_ddAC2(psi.be, o1, o2, envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi))

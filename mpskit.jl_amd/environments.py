@@ -77,9 +77,24 @@ class FinEnv:
         self.rdeps[ind] = None
 
 
+class MultipleEnvironments:
+    """MultipleEnvironments (src/environments/multipleenv.jl:1-62): one environment object per LazySum term."""
+
+    def __init__(self, H, envs):
+        self.H, self.envs = H, list(envs)
+
+    def recalculate(self, psi, tol=None):
+        for e in self.envs:
+            e.recalculate(psi, tol)
+        return self
+
+
 def environments(psi, H, **kw):
-    """environments(psi, H)  (FinEnv.jl:41-70 / mpohaminfenv.jl:40-44)."""
+    """environments(psi, H)  (FinEnv.jl:41-70 / mpohaminfenv.jl:40-44 / multipleenv.jl:30-34)."""
     from .states import FiniteMPS
+    from .operators import LazySum
+    if isinstance(H, LazySum):
+        return MultipleEnvironments(H, [environments(psi, h, **kw) for h in H])
     if isinstance(psi, FiniteMPS):
         return FinEnv(psi, H)
     return MPOHamInfEnv(psi, H, **kw)

@@ -147,3 +147,20 @@ def hubbard(t=1.0, U=4.0, be=None):
     return MPOHamiltonian({(0, 0): 1.0, (5, 5): 1.0, (0, 5): U * (nu @ nd),
                            (0, 1): -t * (cu.T @ F), (1, 5): cu, (0, 2): t * (cu @ F), (2, 5): cu.T,
                            (0, 3): -t * (cd.T @ F), (3, 5): cd, (0, 4): t * (cd @ F), (4, 5): cd.T}, be=be)
+
+
+class LazySum(list):
+    """LazySum(ops[, fs])  (src/operators/lazysum.jl:16-59): a sum of operators that is never formed; every
+    effective Hamiltonian / expectation value is the (weighted) sum of the terms' own (multipleenv.jl,
+    derivatives.jl:310-323).  fs: optional scalar prefactors (MultipliedOperator with constant factors)."""
+
+    def __init__(self, ops, fs=None):
+        super().__init__(ops)
+        self.fs = [1.0] * len(self) if fs is None else [float(f) for f in fs]
+        if len(self.fs) != len(self):
+            raise ValueError("LazySum: one prefactor per operator")
+
+    def __add__(self, other):
+        if isinstance(other, LazySum):
+            return LazySum(list(self) + list(other), self.fs + other.fs)
+        return LazySum(list(self) + [other], self.fs + [1.0])

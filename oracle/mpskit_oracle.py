@@ -984,6 +984,75 @@ def mps_to_vector(psi):
 
 
 # --------------------------------------------------------------------------------------
+# changebonds (src/algorithms/changebonds/optimalexpand.jl, svdcut.jl)
+# --------------------------------------------------------------------------------------
+
+def leftnull(A):
+    """TensorKit leftnull(t; QR): orthonormal basis of the complement of range(A[(a,s), b]); [a,s,n]."""
+    Dl, d, Dr = A.shape
+    Qf, _ = np.linalg.qr(A.reshape(Dl * d, Dr), mode="complete")
+    return Qf[:, Dr:].reshape(Dl, d, Dl * d - Dr)
+
+
+def rightnull(A):
+    """rightnull!(_transpose_tail(A)): orthonormal rows spanning the complement of the rows of A[a, (s,b)]; [n,s,b]."""
+    Dl, d, Dr = A.shape
+    Qf, _ = np.linalg.qr(A.reshape(Dl, d * Dr).conj().T, mode="complete")
+    return Qf[:, Dl:].conj().T.reshape(d * Dr - Dl, d, Dr)
+
+
+def changebonds_optimalexpand(psi, H, envs=None, truncdim=1):
+    """changebonds!(psi::FiniteMPS, H, OptimalExpand(trscheme = truncdim(k)))  (optimalexpand.jl:72-102):
+    per bond, the dominant right singular vectors of NL^dag (H_AC2 AC2) NR^dag are appended to AR[i+1]
+    (zero columns to AC[i]); the state itself is unchanged."""
+    psi = psi.copy()
+    envs = FinEnv(psi, H) if envs is None else envs
+    L = len(psi)
+    for i in range(L - 1):
+        ac, ar = psi.AC(i), psi.AR(i + 1)
+        ac2 = np.einsum("asm,mrb->asbr", ac, ar)
+        ac2 = dAC2(ac2, envs.opp[i], envs.opp[i + 1], envs.leftenv(i, psi), envs.rightenv(i + 1, psi))
+        NL, NR = leftnull(ac), rightnull(ar)
+        inter = np.einsum("asn,asbr,prb->np", np.conj(NL), ac2, np.conj(NR))
+        if min(inter.shape) == 0:
+            continue
+        _, S, Vh = np.linalg.svd(inter, full_matrices=False)
+        k = min(truncdim, len(S))
+        ar_re = np.einsum("kp,prb->krb", Vh[:k], NR)
+        Dl, d, Dm = ac.shape
+        nal, nc = leftorth(np.concatenate([ac, np.zeros((Dl, d, k), dtype=ac.dtype)], axis=2))
+        nar = np.concatenate([ar, ar_re], axis=0)
+        psi.set_AC(i, (nal, nc))
+        psi.set_AC(i + 1, (nc, nar))
+    return psi, envs
+
+
+def changebonds_svdcut(psi, truncdim=None, truncerr=None):
+    """changebonds!(psi::FiniteMPS, SvdCut(trscheme))  (svdcut.jl:14-23)."""
+    psi = psi.copy()
+    L = len(psi)
+    for i in range(L - 2, -1, -1):
+        c = psi.CR(i)
+        U, S, Vh = np.linalg.svd(c, full_matrices=False)
+        k = len(S)
+        if truncdim is not None:
+            k = min(k, truncdim)
+        if truncerr is not None:
+            tot = np.linalg.norm(S)
+            while k > 1 and np.linalg.norm(S[k - 1:]) <= truncerr * tot:
+                k -= 1
+        U, S, Vh = U[:, :k], S[:k], Vh[:k]
+        al = np.einsum("asb,bk->ask", psi.AL(i), U)
+        ar = np.einsum("kb,bsc->ksc", Vh, psi.AR(i + 1))
+        cm = np.diag(S).astype(c.dtype)
+        psi.set_AC(i, (al, cm))
+        psi.set_AC(i + 1, (cm, ar))
+    n = psi.norm()                     # normalize!(psi)
+    psi.set_AC(L - 1, psi.AC(L - 1) / n)
+    return psi
+
+
+# --------------------------------------------------------------------------------------
 # InfiniteMPS, uniform gauge, infinite environments, VUMPS
 # (src/states/infinitemps.jl, ortho.jl, src/environments/mpohaminfenv.jl, vumps.jl)
 # --------------------------------------------------------------------------------------

@@ -256,3 +256,75 @@ def test_infinite_tdvp_imaginary_time_lowers_energy(be):
         es.append(float(np.sum(mk.expectation_value(psi, H, envs))))
     assert all(b < a + 1e-10 for a, b in zip(es, es[1:]))
     assert -1.0635444099734 - 1e-6 <= es[-1] < -1.05
+
+
+def test_changebonds_optimalexpand_and_svdcut(be):
+    """optimalexpand.jl:72-102 / svdcut.jl:14-23 on the HIP path vs the oracle: the expansion leaves the state
+    untouched, grows the same bonds by the same amount, appends the same row space to AR[i+1], and 1-site
+    DMRG from the expanded state converges to the oracle's energy; SvdCut truncates back."""
+    mk = _mk()
+    L, D, kx = 8, 4, 3
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)
+    rng = np.random.default_rng(41)
+    dims = mo.FiniteMPS.random(L, 2, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.random((1 if i == 0 else dims[i - 1], 2, dims[i])) for i in range(L)]
+    pg, po = mk.FiniteMPS(As, normalize=True, be=be), mo.FiniteMPS(As, normalize=True)
+    v0 = mo.mps_to_vector(po)
+    pg2, eg = mk.changebonds(pg, Hg, mk.OptimalExpand(trunc_dim=kx))
+    po2, eo = mo.changebonds_optimalexpand(po, Ho, truncdim=kx)
+    assert pg2.bond_dims() == po2.bond_dims() and max(pg2.bond_dims()) > D
+    assert np.abs(_dense_state(be, pg2) - v0).max() < 1e-13          # same physical state
+    assert abs(pg2.norm() - 1) < 1e-13
+    # (the zero-weight columns QRpos appends to AL[i] are an arbitrary orthonormal completion -- LAPACK's in the
+    #  reference, ours here -- and later bonds see them through GL, so intermediate sweeps are not comparable
+    #  element-wise; the gauge identities and the converged energy are)
+    for i in range(L):
+        al, ar = be.download(pg2.AL(i)), be.download(pg2.AR(i))
+        assert np.abs(np.einsum("asb,asc->bc", al, al) - np.eye(al.shape[2])).max() < 1e-12
+        assert np.abs(np.einsum("asb,csb->ac", ar, ar) - np.eye(ar.shape[0])).max() < 1e-12
+    # expanding (twice) by more than the null spaces hold saturates every bond ([2,4,8,16,8,4,2]); 1-site DMRG from
+    # there must reach the exact ground state (1-site DMRG alone cannot leave D = 4)
+    pf, ef = mk.changebonds(pg, Hg, mk.OptimalExpand(trunc_dim=16))     # each pass can at most double a bond
+    pf, ef = mk.changebonds(pf, Hg, mk.OptimalExpand(trunc_dim=16), ef)
+    assert pf.bond_dims()[:-1] == [2, 4, 8, 16, 8, 4, 2]
+    assert np.abs(_dense_state(be, pf) - v0).max() < 1e-13
+    p3, e3, eps = mk.find_groundstate(pf, Hg, mk.DMRG(tol=1e-11, maxiter=30))
+    E3 = float(np.sum(mk.expectation_value(p3, Hg, e3)))
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
+    assert eps < 1e-9 and abs(E3 - e0) <= 1e-9 * abs(e0)
+    _, _, _, log_noexp = mo.dmrg(po, Ho, tol=1e-10, maxiter=10)
+    assert log_noexp[-1][1] > e0 + 1e-4
+    # SvdCut back to D: same state as the oracle's cut (both start from the expanded state)
+    pc = mk.changebonds(pg2, mk.SvdCut(trunc_dim=D))
+    oc = mo.changebonds_svdcut(po2, truncdim=D)
+    assert pc.bond_dims() == oc.bond_dims() and max(pc.bond_dims()) <= D
+    assert np.abs(_dense_state(be, pc) - mo.mps_to_vector(oc)).max() < 1e-12
+    assert np.abs(_dense_state(be, pc) - v0).max() < 1e-12            # the added directions carried no weight
+
+
+def test_lazysum_drivers(be):
+    """LazySum / MultipleEnvironments through the HIP path (test/operators.jl:173-280, test/algorithms.jl:113,143):
+    finite DMRG and an imaginary-time TDVP step with LazySum([H_zz, H_x]) agree with the summed TFI Hamiltonian;
+    VUMPS with the lazy sum reaches the recorded iTFI energy."""
+    mk = _mk()
+    g = 0.5
+    Hzz, Hx = mk.transverse_field_ising(1.0, 0.0, be=be), mk.transverse_field_ising(0.0, g, be=be)
+    Hfull = mk.transverse_field_ising(1.0, g, be=be)
+    Hl = mk.LazySum([Hzz, Hx])
+    psi = mk.FiniteMPS.random(10, 2, 8, np.random.default_rng(3), be=be)
+    x = psi.AC(4)
+    yl = be.download(mk.ddAC(4, psi, Hl, mk.environments(psi, Hl))(x))
+    yf = be.download(mk.ddAC(4, psi, Hfull, mk.environments(psi, Hfull))(x))
+    assert np.abs(yl - yf).max() < 1e-12 * np.abs(yf).max()
+    pl, el, epsl = mk.find_groundstate(psi, Hl, mk.DMRG(tol=1e-10, maxiter=10))
+    pf, ef, epsf = mk.find_groundstate(psi, Hfull, mk.DMRG(tol=1e-10, maxiter=10))
+    El, Ef = float(np.sum(mk.expectation_value(pl, Hl, el))), float(np.sum(mk.expectation_value(pf, Hfull, ef)))
+    assert epsl < 1e-9 and abs(El - Ef) <= ETOL * abs(Ef)
+    tl, _ = mk.timestep(psi, Hl, 0.0, -0.1j, mk.TDVP())
+    tf, _ = mk.timestep(psi, Hfull, 0.0, -0.1j, mk.TDVP())
+    assert abs(tl.norm() - tf.norm()) < 1e-11
+    assert np.abs(be.download(tl.AC(5)) - be.download(tf.AC(5))).max() < 1e-10
+    A = np.random.default_rng(9).random((10, 2, 10))
+    pv, ev, epsv = mk.find_groundstate(mk.InfiniteMPS.from_tensors([A], be=be), Hl, mk.VUMPS(tol=1e-10, maxiter=40))
+    assert epsv < 1e-9
+    assert abs(float(np.sum(mk.expectation_value(pv, Hl, ev))) - (-1.063544409973)) < 5e-12

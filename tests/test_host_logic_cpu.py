@@ -144,3 +144,28 @@ def test_tdvp_driver_matches_oracle(cb):
     assert np.abs(vec.reshape(-1) - ex).max() < 1e-11
     with pytest.raises(NotImplementedError):
         mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP())
+
+
+def test_lazysum_matches_summed_hamiltonian(cb):
+    """lazysum.jl / multipleenv.jl / derivatives.jl:310-323 (reference test: test/operators.jl:173-280):
+    LazySum([H_zz, H_x]) acts like the TFI Hamiltonian H_zz + H_x -- matvec linearity, expectation values and the
+    DMRG ground state energy."""
+    g = 0.7
+    Hzz, Hx = mk.transverse_field_ising(1.0, 0.0, be=cb), mk.transverse_field_ising(0.0, g, be=cb)
+    Hfull, Ho = mk.transverse_field_ising(1.0, g, be=cb), mo.tfi_mpo(1.0, g)
+    Hl = mk.LazySum([Hzz, Hx])
+    pg, po = _pair(cb, L=6, D=8, seed=13)
+    el, ef = mk.environments(pg, Hl), mk.environments(pg, Hfull)
+    assert isinstance(el, mk.MultipleEnvironments)
+    x = pg.AC(2)
+    yl, yf = cb.download(mk.ddAC(2, pg, Hl, el)(x)), cb.download(mk.ddAC(2, pg, Hfull, ef)(x))
+    assert np.abs(yl - yf).max() < 1e-12 * max(1.0, np.abs(yf).max())
+    assert np.abs(mk.expectation_value(pg, Hl, el) - mk.expectation_value(pg, Hfull, ef)).max() < 1e-12
+    p, e, eps = mk.find_groundstate(pg, Hl, mk.DMRG(tol=1e-10, maxiter=8))
+    E = float(np.sum(mk.expectation_value(p, Hl, e)))
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, 6))[0]
+    assert eps < 1e-9 and abs(E - e0) < 1e-9
+    # prefactors: LazySum([H, H], [0.25, 0.75]) == H
+    H2 = mk.LazySum([Hfull, Hfull], [0.25, 0.75])
+    y2 = cb.download(mk.ddAC(2, pg, H2, mk.environments(pg, H2))(x))
+    assert np.abs(y2 - yf).max() < 1e-12 * max(1.0, np.abs(yf).max())

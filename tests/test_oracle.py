@@ -185,3 +185,22 @@ def test_tdvp_real_time_conserves_energy():
     e1 = np.sum(mo.expectation_value(p1, H, envs)).real
     assert abs(e1 - e0) < 1e-8 * max(1.0, abs(e0))
     assert abs(p1.norm() - 1) < 1e-10
+
+
+def test_changebonds_restatement():
+    """optimalexpand.jl:72-102 / svdcut.jl:14-23: expansion keeps the state and the energy, grows the bonds,
+    helps the next DMRG sweeps; SvdCut of the zero-weight directions restores the original state."""
+    L = 8
+    H = mo.heisenberg_mpo(0.5)
+    psi = mo.FiniteMPS.random(L, 2, 4, np.random.default_rng(2))
+    v0 = mo.mps_to_vector(psi)
+    p2, envs = mo.changebonds_optimalexpand(psi, H, truncdim=3)
+    assert np.abs(mo.mps_to_vector(p2) - v0).max() < 1e-14
+    assert max(p2.bond_dims()) == 7 and abs(p2.norm() - 1) < 1e-14
+    e0 = np.sum(mo.expectation_value(psi, H, mo.FinEnv(psi, H)))
+    assert abs(np.sum(mo.expectation_value(p2, H, envs)) - e0) < 1e-12
+    p3 = mo.changebonds_svdcut(p2, truncdim=4)
+    assert max(p3.bond_dims()) == 4 and np.abs(mo.mps_to_vector(p3) - v0).max() < 1e-13
+    _, _, _, l1 = mo.dmrg(psi, H, tol=1e-10, maxiter=4)
+    _, _, _, l2 = mo.dmrg(p2, H, tol=1e-10, maxiter=4)
+    assert l2[-1][1] < l1[-1][1]
