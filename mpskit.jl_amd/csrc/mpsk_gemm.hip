@@ -168,6 +168,26 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
   }
 }
 
+// XCD-ordered linear tile index t -> tile coordinates.  Tiles [x*q, (x+1)*q) run on XCD x (q = ntiles / 8).
+// With an XCD grid gx x gy each XCD owns a (tilesM/gx) x (tilesN/gy) RECTANGLE of the tile grid, so its private L2
+// only has to stream M/gx rows of A and N/gy columns of B instead of all of A (a column strip): the PMC passes
+// showed 5-10x the compulsory L2->fabric traffic with strip chunks (profiles/r01_pmc_traffic.json).
+__device__ __forceinline__ void tile_coords(const GemmArgs& g, int t, int tilesM, int tilesN, int* bm, int* bn) {
+  if (g.xcd_gx > 0) {
+    const int q = (tilesM * tilesN) >> 3;
+    const int xcd = t / q, pos = t - xcd * q;
+    const int rm = tilesM / g.xcd_gx, rn = tilesN / g.xcd_gy;
+    const int xi = xcd % g.xcd_gx, yi = xcd / g.xcd_gx;
+    const int ln = pos / rm, lm = pos - ln * rm;
+    *bm = xi * rm + lm;
+    *bn = yi * rn + ln;
+    (void)rn;
+  } else {
+    *bn = t / tilesM;
+    *bm = t - *bn * tilesM;
+  }
+}
+
 // epilogue: lane holds C[m = .. + fr][n = .. + fq + 4*reg]
 template <int BM, int BN, bool ALIGNED>
 __device__ __forceinline__ void gemm_store_c(const GemmArgs& g, double* __restrict__ Cb, int z, int m0, int n0,
@@ -224,7 +244,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, pos = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   }
-  const int bm = bid % tilesM, bn = bid / tilesM;
+  int bm, bn;
+  tile_coords(g, bid, tilesM, tilesN, &bm, &bn);
   const int z = blockIdx.y;
   const int m0 = bm * BM, n0 = bn * BN;
   const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
@@ -270,7 +291,8 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
     const int kt0 = u - tz * KT;
     const int kt1 = (uend - u < KT - kt0) ? kt0 + (uend - u) : KT;
     const int z = tz / ntiles, tile = tz - z * ntiles;
-    const int bn = tile / tilesM, bm = tile - bn * tilesM;
+    int bm, bn;
+    tile_coords(g, tile, tilesM, tilesN, &bm, &bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
     const double* Bb = g.B + (g.tabB ? g.tabB[z] : (int64_t)z * g.bsB);
@@ -331,7 +353,8 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs g) {
   const int u0 = tz * KT, u1 = u0 + KT;
   const int i = u0 / g.sk_units + 1;           // first (logical) share that can start inside (u0, u1)
   if (i * g.sk_units >= u1) return;            // tile not split
-  const int bm = tile % tilesM, bn = tile / tilesM;
+  int bm, bn;
+  tile_coords(g, tile, tilesM, tilesN, &bm, &bn);
   const int m0 = bm * BM, n0 = bn * BN;
   double* Cb = g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC);
   for (int e = threadIdx.x; e < BM * BN; e += 256) {
@@ -502,6 +525,7 @@ void gemm_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 // MPSK_STREAMK=1 enables it (single-stream use only: the partial-tile workspace is per device).
 static bool g_sk_enabled = (getenv("MPSK_STREAMK") != nullptr) && (getenv("MPSK_STREAMK")[0] == '1');
 void gemm_enable_streamk(bool on) { g_sk_enabled = on; }
+static bool g_xcd_grid_enabled = (getenv("MPSK_XCDGRID") == nullptr) || (getenv("MPSK_XCDGRID")[0] != '0');
 static bool g_splitk_enabled = (getenv("MPSK_SPLITK") == nullptr) || (getenv("MPSK_SPLITK")[0] != '0');
 constexpr size_t SK_WS_DOUBLES = (size_t)1024 * 128 * 128 / 2;   // 512 slots of 128x128 == 2048 slots of 64x64
 // partial-tile workspace: one per (device, stream) so that concurrent streams never share slots;
@@ -555,6 +579,21 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
       if (f >= 2) {
         double* ws = sk_workspace(s);
         if (ws) { g.sk_units = (KT + f - 1) / f; g.sk_ws = ws; }
+      }
+    }
+  }
+  {  // XCD grid: minimise the operand rows + columns an XCD's L2 has to stream, M/gx + N/gy
+    const int tM = (g.M + bm - 1) / bm, tN = (g.N + bn - 1) / bn;
+    g.xcd_gx = g.xcd_gy = 0;
+    const bool chunks_ok = ((int64_t)tM * tN) % 8 == 0 &&
+                           (g.sk_units == 0 || (((g.K + BK - 1) / BK) * g.nseg) % g.sk_units == 0);
+    if (chunks_ok && g_xcd_grid_enabled) {
+      double best = 0.0;
+      const int cand[4][2] = {{1, 8}, {2, 4}, {4, 2}, {8, 1}};
+      for (int c = 0; c < 4; ++c) {
+        if (tM % cand[c][0] || tN % cand[c][1]) continue;
+        const double cost = (double)g.M / cand[c][0] + (double)g.N / cand[c][1];
+        if (g.xcd_gx == 0 || cost < best) { best = cost; g.xcd_gx = cand[c][0]; g.xcd_gy = cand[c][1]; }
       }
     }
   }

@@ -32,6 +32,8 @@ struct GemmArgs {
   // stream-K (set by gemm_f64 itself): units of k-tiles per workgroup and the partial-tile workspace
   int sk_units;
   double* sk_ws;
+  // XCD grid (set by gemm_f64): the 8 XCDs' tile chunks are xcd_gx x xcd_gy rectangles of the tile grid (0: linear)
+  int xcd_gx, xcd_gy;
   int tag;                   // 1: matvec-stage launch (own kernel symbol + event profile)
   int tabs_even;             // caller guarantees every tabA/tabB entry is even (16-B aligned operands)
 };

@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name") or row.get("Kernel Name")
             cn, cv = row.get("Counter_Name"), float(row.get("Counter_Value", 0))
-            short = name.split("(")[0].replace("void ", "").replace("mpsk::", "")
+            short = name.split("(")[0].replace("void ", "").replace("mpsk::", "").replace(" ", "")   # bench.py's kernel key
             a = acc.setdefault(short, {}).setdefault(cn, [0.0, 0])
             a[0] += cv; a[1] += 1
 out = {}
@@ -17,5 +17,7 @@ for k, v in acc.items():
     fetch = v.get("FETCH_SIZE", [0, 1]); write = v.get("WRITE_SIZE", [0, 1])
     rd = 2.0 * fetch[0] / max(fetch[1], 1) * 1024.0
     wr = write[0] / max(write[1], 1) * 1024.0
-    out[k] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_sampled": max(fetch[1], write[1])}
+    out[k] = rd + wr                                        # what bench.py puts into roofline.traffic
+    out[k + "/detail"] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+                          "launches_sampled": max(fetch[1], write[1])}
 print(json.dumps(out, indent=1, sort_keys=True))
