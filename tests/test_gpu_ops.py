@@ -344,3 +344,53 @@ def test_tsvd_graded_and_rank_deficient_preconditioned(be):
     assert np.abs(S - Sr).max() < 1e-12 * Sr[0]
     assert relerr((U * S) @ Vh, B) < 1e-12
     assert np.abs(U[:, :100].T @ U[:, :100] - np.eye(100)).max() < 1e-12
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB", [(1024, 512, 2048, 0, 0),     # split-K (64 tiles x 128 k-tiles), XCD grid
+                                          (512, 512, 4096, 1, 0),      # TN Gram shape, split-K
+                                          (2048, 1024, 256, 0, 0),     # 512 tiles, XCD rectangles 4 x 2
+                                          (1024, 2048, 128, 0, 1),     # NT, rectangles 2 x 4
+                                          (1032, 520, 1040, 0, 0),     # ragged -> unaligned kernel, linear tile order
+                                          (4096, 64, 64, 0, 0)])       # tall skinny (SVD update shape)
+def test_gemm_large_paths(be, M, N, K, tA, tB):
+    """Every launch-path of the GEMM core (split-K + fixup, XCD-rectangle tile map, unaligned loaders) against
+    numpy at sizes that trigger it; also with the remap / split switched off via the environment-free knobs."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    A = rng.standard_normal((K, M) if tA else (M, K))
+    B = rng.standard_normal((N, K) if tB else (K, N))
+    C0 = rng.standard_normal((M, N))
+    ref = 1.1 * (A.T if tA else A) @ (B.T if tB else B) + 0.5 * C0
+    dA, dB = be.upload(A), be.upload(B)
+    for tile in ((0, 0), (64, 64), (128, 128)):
+        be.lib.mpsk_ctx_force_tile(be.ctx, *tile)
+        try:
+            out = be.upload(C0)
+            be.gemm(dA, dB, transA=bool(tA), transB=bool(tB), alpha=1.1, beta=0.5, out=out)
+            assert relerr(be.download(out), ref) < RTOL * K
+        finally:
+            be.lib.mpsk_ctx_force_tile(be.ctx, 0, 0)
+
+
+def test_abi_error_behaviour(be):
+    """Errors are return codes + mpsk_last_error (no exceptions across the boundary): bad arguments are
+    rejected before any launch, the message names the check, and the context stays usable."""
+    import ctypes as C
+    from mpskit_jl_amd._lib import MpskError
+    lib = be.lib
+    A = be.upload(np.random.default_rng(0).random((8, 4)))
+    Q, R = be.empty(8, 4), be.empty(4, 4)
+    assert lib.mpsk_qrpos(be.ctx, 4, 8, A.ptr, 4, Q.ptr, 4, R.ptr, 8) == 1          # m < n
+    assert b"m >= n" in lib.mpsk_last_error()
+    assert lib.mpsk_qrpos(be.ctx, 8, 4, A.ptr, 4, Q.ptr, 8, R.ptr, 4) == 1          # lda < m
+    assert lib.mpsk_qrpos(be.ctx, 8, 4, None, 8, Q.ptr, 8, R.ptr, 4) == 1           # NULL
+    assert lib.mpsk_lqpos(be.ctx, 8, 4, A.ptr, 8, R.ptr, 8, Q.ptr, 8) == 1          # m > n
+    k, disc = C.c_int(0), C.c_double(0.0)
+    assert lib.mpsk_tsvd(be.ctx, 8, 4, A.ptr, 8, Q.ptr, 8, R.ptr, R.ptr, 4, 0, -1.0, C.byref(k), C.byref(disc)) == 1
+    assert lib.mpsk_gemm(be.ctx, 0, 0, 0, 4, 4, 1.0, A.ptr, 8, A.ptr, 8, 0.0, Q.ptr, 8) == 1
+    assert lib.mpsk_ctx_set_qr_mode(be.ctx, 7) == 1
+    with pytest.raises(MpskError):
+        be.upload(np.ones((2, 2)) * (1 + 1j))                                       # complex128 is not built
+    with pytest.raises(AssertionError):
+        be.dC(be.empty(3, 4, 4), be.empty(2, 5, 5), be.empty(4, 5))                 # level count mismatch
+    Qg, Rg = be.qrpos(A)                                                            # context still fine
+    assert relerr(be.download(Qg) @ be.download(Rg), be.download(A)) < 1e-13
