@@ -147,6 +147,8 @@ def find_groundstate(psi, H, alg=None, envs=None):
         return _dmrg2(psi.copy(), H, alg, envs)
     if isinstance(alg, VUMPS):
         return _vumps(psi, H, alg, envs)
+    if isinstance(alg, IDMRG1):
+        return _idmrg1(psi, H, alg, envs)
     raise TypeError(f"unknown algorithm {alg!r}")
 
 
@@ -436,3 +438,81 @@ def time_evolve(psi, H, t_span, alg=None, envs=None):
         if alg.finalize is not None:
             psi, envs = alg.finalize(t0, psi, H, envs)
     return psi, envs
+
+
+# ---- IDMRG1 (src/algorithms/groundstate/idmrg.jl:21-77, src/environments/idmrgenv.jl) ---------------------
+
+@dataclass
+class IDMRG1:  # idmrg.jl:13-19
+    tol: float = 1e-12
+    tol_gauge: float = 1e-14
+    maxiter: int = 100
+    krylovdim: int = 30
+    verbosity: int = 0
+    eig_tol_min: float = 1e-12
+    eig_tol_max: float = 1e-5
+    eig_tol_factor: float = 1e-5
+
+
+class IDMRGEnv:
+    """idmrgenv.jl:6-49: private copies of the converged infinite environments, updated by hand with the
+    MPO transfer kernels (no regularisation, no dependency checks)."""
+
+    def __init__(self, psi, env: MPOHamInfEnv):
+        if env.dependency is not psi:
+            env.recalculate(psi)
+        be, n = psi.be, len(psi)
+        self.be, self.n, self.H = be, n, env.H
+        self.opp = [env.H[s] for s in range(n)]
+        self.lw = [be.copy(env._assemble("l", s, n)) for s in range(n)]
+        self.rw = [be.copy(env._assemble("r", s, n)) for s in range(n)]
+
+    def leftenv(self, pos, psi=None):
+        return self.lw[pos % self.n]
+
+    def rightenv(self, pos, psi=None):
+        return self.rw[pos % self.n]
+
+    def update_leftenv(self, psi, pos):   # idmrgenv.jl:69-72 : lw[pos] = lw[pos-1] * TM(AL[pos-1], H[pos-1])
+        p = (pos - 1) % self.n
+        self.lw[pos % self.n] = self.be.transfer_left(self.opp[p], self.lw[p], psi.AL[p], psi.AL[p])
+
+    def update_rightenv(self, psi, pos):  # idmrgenv.jl:64-67 : rw[pos] = TM(AR[pos+1], H[pos+1]) * rw[pos+1]
+        p = (pos + 1) % self.n
+        self.rw[pos % self.n] = self.be.transfer_right(self.opp[p], self.rw[p], psi.AR[p], psi.AR[p])
+
+
+def _idmrg1(ost, H, alg: IDMRG1, oenvs=None):  # idmrg.jl:21-77
+    from .states import rightorth
+    be = ost.be
+    oenvs = MPOHamInfEnv(ost, H) if oenvs is None else oenvs
+    eps = _calc_galerkin_inf(ost, oenvs)
+    n = len(ost)
+    psi = InfiniteMPS(list(ost.AL), list(ost.AR), list(ost.CR), list(ost.AC), be)
+    envs = IDMRGEnv(ost, oenvs)
+    ws = krylov.KrylovWorkspace(be)
+    t0 = time.time()
+    for it in range(1, alg.maxiter + 1):
+        eig = Arnoldi(tol=updatetol(alg.eig_tol_min, alg.eig_tol_max, alg.eig_tol_factor, it, eps), krylovdim=alg.krylovdim)
+        c_cur = psi.CR[n - 1]
+        for pos in range(n):
+            _, psi.AC[pos] = fixedpoint(be, ddAC(pos, psi, H, envs), psi.AC[pos], eig, ws)
+            psi.AL[pos], psi.CR[pos] = leftorth(be, psi.AC[pos])
+            envs.update_leftenv(psi, pos + 1)
+        for pos in range(n - 1, -1, -1):
+            _, psi.AC[pos] = fixedpoint(be, ddAC(pos, psi, H, envs), psi.AC[pos], eig, ws)
+            psi.CR[(pos - 1) % n], psi.AR[pos] = rightorth(be, psi.AC[pos])
+            envs.update_rightenv(psi, pos - 1)
+        new = psi.CR[n - 1]
+        if new.shape == c_cur.shape:
+            diff = be.copy(new)
+            be.axpby(-1.0, c_cur, 1.0, diff)
+            eps = be.norm(diff)
+        else:
+            eps = 1.0
+        if alg.verbosity >= 3:
+            print(f"[ Info: IDMRG {it:3d}:\terr = {eps:.10e}\ttime = {time.time() - t0:.2f} sec", flush=True)
+        if eps < alg.tol:
+            break
+    nst = InfiniteMPS.from_tensors(psi.AR, tol=alg.tol_gauge, be=be)
+    return nst, MPOHamInfEnv(nst, H), eps

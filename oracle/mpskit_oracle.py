@@ -1409,3 +1409,40 @@ def vumps(psi, H, tol=1e-12, maxiter=100, krylovdim=30, verbose=False, fixed_mat
         if eps <= tol:
             break
     return psi, envs, eps, log
+
+
+# --------------------------------------------------------------------------------------
+# IDMRG1 (src/algorithms/groundstate/idmrg.jl:21-77, src/environments/idmrgenv.jl)
+# --------------------------------------------------------------------------------------
+
+def idmrg1(psi, H, tol=1e-12, tol_gauge=1e-14, maxiter=100, krylovdim=30, verbose=False):
+    """find_groundstate(psi::InfiniteMPS, H, IDMRG1()): sweeps over the unit cell with manually updated copies of
+    the converged infinite environments (no regularisation: the energy accumulates in them); converged when the
+    bond matrix CR[0] stops changing; returns the gauge-fixed state and fresh environments."""
+    envs0 = MPOHamInfEnv(psi, H)
+    eps = calc_galerkin_inf(psi, envs0)
+    n, odim = len(psi), H.odim
+    AL, AR, AC, CR = list(psi.AL), list(psi.AR), list(psi.AC), list(psi.CR)
+    lw = [[envs0.lw[i][s].copy() for i in range(odim)] for s in range(n)]      # lw[site][level]
+    rw = [[envs0.rw[i][s].copy() for i in range(odim)] for s in range(n)]
+    for it in range(1, maxiter + 1):
+        eig_tol = updatetol(1e-12, 1e-5, 1e-5, it, eps)
+        C_current = CR[n - 1]
+        for pos in range(n):
+            GL, GR, slc = lw[pos], rw[pos], H[pos]
+            _, AC[pos], _ = eigsolve_sr(lambda x: dAC(x, slc, GL, GR), AC[pos], tol=eig_tol, krylovdim=krylovdim)
+            AL[pos], CR[pos] = leftorth(AC[pos])
+            lw[(pos + 1) % n] = transfer_left(lw[pos], H[pos], AL[pos], AL[pos])
+        for pos in range(n - 1, -1, -1):
+            GL, GR, slc = lw[pos], rw[pos], H[pos]
+            _, AC[pos], _ = eigsolve_sr(lambda x: dAC(x, slc, GL, GR), AC[pos], tol=eig_tol, krylovdim=krylovdim)
+            CR[(pos - 1) % n], AR[pos] = rightorth(AC[pos])
+            rw[(pos - 1) % n] = transfer_right(rw[pos], H[pos], AR[pos], AR[pos])
+        eps = float(np.linalg.norm(C_current - CR[n - 1])) if C_current.shape == CR[n - 1].shape else 1.0
+        if verbose:
+            print(f"IDMRG {it:3d}: err = {eps:.10e}")
+        if eps < tol:
+            break
+    nst = InfiniteMPS.from_tensors(AR, tol=tol_gauge)
+    nenvs = MPOHamInfEnv(nst, H)
+    return nst, nenvs, eps

@@ -328,3 +328,21 @@ def test_lazysum_drivers(be):
     pv, ev, epsv = mk.find_groundstate(mk.InfiniteMPS.from_tensors([A], be=be), Hl, mk.VUMPS(tol=1e-10, maxiter=40))
     assert epsv < 1e-9
     assert abs(float(np.sum(mk.expectation_value(pv, Hl, ev))) - (-1.063544409973)) < 5e-12
+
+
+def test_idmrg1_reference_recorded_energy(be):
+    """idmrg.jl:21-77 on the HIP path: infinite TFI (|g| = 0.5), D = 10 converges to the energy the reference's docs
+    record for this model (-1.063544409973, 3.ising-dqpt/index.md:105-118) and to the oracle's IDMRG1; two-site unit
+    cell as well."""
+    mk = _mk()
+    H = mk.transverse_field_ising(1.0, 0.5, be=be)
+    A = np.random.default_rng(9).random((10, 2, 10))
+    p, e, eps = mk.find_groundstate(mk.InfiniteMPS.from_tensors([A], be=be), H, mk.IDMRG1(tol=1e-10, maxiter=300))
+    E = float(np.sum(mk.expectation_value(p, H, e)))
+    assert eps < 1e-10 and abs(E - (-1.063544409973)) < 5e-12
+    po, eo, epso = mo.idmrg1(mo.InfiniteMPS.from_tensors([A]), mo.tfi_mpo(1.0, 0.5), tol=1e-10, maxiter=300)
+    assert abs(E - float(np.sum(mo.expectation_value_inf(po, mo.tfi_mpo(1.0, 0.5), eo)).real)) <= ETOL * abs(E)
+    B = np.random.default_rng(10).random((8, 2, 8))
+    p2, e2, eps2 = mk.find_groundstate(mk.InfiniteMPS.from_tensors([B, B.copy()], be=be), H, mk.IDMRG1(tol=1e-10, maxiter=300))
+    E2 = mk.expectation_value(p2, H, e2)
+    assert eps2 < 1e-10 and abs(float(np.sum(E2)) / 2 - (-1.0635444099)) < 1e-8

@@ -204,3 +204,12 @@ def test_changebonds_restatement():
     _, _, _, l1 = mo.dmrg(psi, H, tol=1e-10, maxiter=4)
     _, _, _, l2 = mo.dmrg(p2, H, tol=1e-10, maxiter=4)
     assert l2[-1][1] < l1[-1][1]
+
+
+def test_idmrg1_restatement_recorded_energy():
+    """idmrg.jl:21-77 restated: iTFI (|g| = 0.5), D = 10 -> the energy recorded in the reference docs."""
+    H = mo.tfi_mpo(1.0, 0.5)
+    A = np.random.default_rng(9).random((10, 2, 10))
+    p, e, eps = mo.idmrg1(mo.InfiniteMPS.from_tensors([A]), H, tol=1e-10, maxiter=300)
+    assert eps < 1e-10
+    assert abs(np.sum(mo.expectation_value_inf(p, H, e)).real - (-1.063544409973)) < 5e-12
