@@ -68,18 +68,20 @@ def updatetol(tol_min, tol_max, factor, it, eps):  # dynamictols.jl:50-53
     return min(max(eps * factor / math.sqrt(it), tol_min), tol_max)
 
 
-def fixedpoint(be, A, x0, alg: Arnoldi, ws=None):
+def fixedpoint(be, A, x0, alg: Arnoldi, ws=None, first_image=None):
     """fixedpoint(A, x0, :SR, alg)  (fixedpoint.jl:19-30); non-convergence only warns."""
     lam, vec, nmv, res = krylov.eigsolve_sr(be, A, x0, tol=alg.tol, krylovdim=alg.krylovdim,
-                                            maxiter=alg.maxiter, fixed_matvecs=alg.fixed_matvecs, ws=ws)
+                                            maxiter=alg.maxiter, fixed_matvecs=alg.fixed_matvecs, ws=ws,
+                                            first_image=first_image)
     return lam, vec
 
 
 # ---- measurements ------------------------------------------------------------------------------
 
-def _galerkin(be, h, ac, al):
-    """|| (1 - AL AL^dag) normalize(h(AC)) ||  for explicit tensors."""
-    g = h(ac)
+def _galerkin(be, h, ac, al, g=None):
+    """|| (1 - AL AL^dag) normalize(h(AC)) ||  for explicit tensors.
+    g: h(AC) up to a positive factor if the caller already has it (the eigensolver's first matvec)."""
+    g = h(ac) if g is None else g
     be.scal(1.0 / be.norm(g), g)
     Dl, d, Dr = al.shape
     alm, gm = al.reshape(Dl * d, Dr), g.reshape(Dl * d, g.shape[2])
@@ -88,17 +90,18 @@ def _galerkin(be, h, ac, al):
     return be.norm(gm)
 
 
-def calc_galerkin(psi, pos, envs, h=None):
+def calc_galerkin(psi, pos, envs, h=None, g=None):
     """|| (1 - AL AL^dag) normalize(H_AC AC) ||   (toolbox.jl:17-22).
-    h: the site's effective Hamiltonian if the caller already built it (same operator)."""
+    h: the site's effective Hamiltonian if the caller already built it (same operator);
+    g: H_AC AC (any positive multiple) if the caller already has it."""
     be = psi.be
     if isinstance(psi, FiniteMPS):
         ac, al = psi.AC(pos), psi.AL(pos)
     else:
         ac, al = psi.AC[pos], psi.AL[pos]
-    if h is None:
+    if h is None and g is None:
         h = ddAC(pos, psi, envs.H, envs)
-    return _galerkin(be, h, ac, al)
+    return _galerkin(be, h, ac, al, g)
 
 
 def expectation_value(psi, H, envs):
@@ -165,14 +168,17 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None, wrap=None):
         if wrap is not None:
             h = wrap(h)
         ac_old = psi.AC(pos)
-        _, vec = fixedpoint(be, h, ac_old, eigalg, ws)
+        # the eigensolver's first matvec is H_AC (AC_old / |AC_old|): exactly the vector calc_galerkin of the old
+        # tensor normalises (toolbox.jl:18), so it is captured instead of applying H_AC to AC_old a second time
+        g = be.empty(*ac_old.shape)
+        _, vec = fixedpoint(be, h, ac_old, eigalg, ws, first_image=g)
         if psi.ALs[pos] is None:
             # right-moving visit: leftorth(old AC) (galerkin projector) and leftorth(new AC) (next AL)
             # are both due -> issue them together; same state as the lazy views would produce
             al_old = psi.set_AC_with_leftorth(pos, vec)
-            eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old))
+            eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old, g))
         else:
-            eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs, h=h))
+            eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs, h=h, g=g))
             psi.set_AC(pos, vec)
     return eps_s
 

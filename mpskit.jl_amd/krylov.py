@@ -27,10 +27,13 @@ class KrylovWorkspace:
 
 
 def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
-                fixed_matvecs=None, ws: KrylovWorkspace | None = None):
+                fixed_matvecs=None, ws: KrylovWorkspace | None = None, first_image: DTensor | None = None):
     """Smallest-real eigenpair of a Hermitian operator: restarted Lanczos/Arnoldi with twice-iterated
     classical Gram-Schmidt and an 'eager' convergence test each step (defaults.jl:33:
     Arnoldi(; tol, maxiter, eager=true)).  matvec(x: DTensor, out: DTensor) -> out.
+    first_image: optional buffer that receives A (x0 / |x0|), the very first matvec of the solve, before it is
+    orthogonalised -- calc_galerkin of the OLD tensor needs exactly this vector (toolbox.jl:18), so the DMRG sweep
+    does not apply the effective Hamiltonian to the same tensor twice.
     Returns (lambda, vec, n_matvecs, residual)."""
     ws = KrylovWorkspace(be) if ws is None else ws
     shape = x0.shape
@@ -47,6 +50,8 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         while k < krylovdim:
             w = V[k + 1]
             matvec(V[k], w)
+            if nmv == 0 and first_image is not None:
+                be.axpby(1.0, w, 0.0, first_image)
             nmv += 1
             h, beta = be.orth_step(V[:k + 1], w)      # CGS2 + normalise, one host sync
             Hm[:k + 1, k] = h
