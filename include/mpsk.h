@@ -131,6 +131,11 @@ int mpsk_qrpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* Q, int
  * leftorth of the old AC (toolbox.jl:17-22) and of the new AC (orthoview.jl:56) at the same moment */
 int mpsk_qrpos2(mpsk_ctx* ctx, int m, int n, const void* A1, int lda1, void* Q1, int ldq1, void* R1, int ldr1,
                 const void* A2, int lda2, void* Q2, int ldq2, void* R2, int ldr2);
+/* QRpos of A1 (m x n) and LQpos of A2 (n x m: A2 = L2 Q2, L2 n x n lower, Q2 n x m) issued together: the
+ * left-moving site update needs leftorth of the old AC (toolbox.jl:17-22) and rightorth of the new AC
+ * (orthoview.jl:52) at the same moment */
+int mpsk_qrlq_pair(mpsk_ctx* ctx, int m, int n, const void* A1, int lda1, void* Q1, int ldq1, void* R1, int ldr1,
+                   const void* A2, int lda2, void* L2, int ldl2, void* Q2, int ldq2);
 /* A (m x n, m <= n) = L (m x m lower) * Q (m x n), diag(L) > 0 */
 int mpsk_lqpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq);
 /* thin SVD of theta (m x n): theta = U diag(S) Vh, S descending.  U: m x kmax, S: kmax, Vh: kmax x n

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mpsk_qrpos": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
     "mpsk_qrpos2": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "mpsk_qrlq_pair": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
     "mpsk_lqpos": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
     "mpsk_tsvd": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                   C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p],

@@ -178,8 +178,9 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None, wrap=None):
             al_old = psi.set_AC_with_leftorth(pos, vec)
             eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old, g))
         else:
-            eps_s[pos] = max(eps_s[pos], calc_galerkin(psi, pos, envs, h=h, g=g))
-            psi.set_AC(pos, vec)
+            # left-moving visit: leftorth(old AC) and rightorth(new AC) are both due -> one paired call
+            al_old = psi.set_AC_with_rightorth(pos, vec)
+            eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old, g))
     return eps_s
 
 

@@ -256,6 +256,15 @@ class Backend:
               "mpsk_qrpos2")
         return Q1, R1, Q2, R2
 
+    def qrlq_pair(self, A1: DTensor, A2: DTensor):
+        """QRpos of A1 (m x n) and LQpos of A2 (n x m) in flight together -> (Q1, R1, L2, Q2)."""
+        m, n = A1.shape
+        assert A2.shape == (n, m) and m >= n
+        Q1, R1, L2, Q2 = self.empty(m, n), self.empty(n, n), self.empty(n, n), self.empty(n, m)
+        check(self.lib.mpsk_qrlq_pair(self.ctx, m, n, A1.ptr, m, Q1.ptr, m, R1.ptr, n, A2.ptr, n, L2.ptr, n, Q2.ptr, n),
+              "mpsk_qrlq_pair")
+        return Q1, R1, L2, Q2
+
     def lqpos(self, A: DTensor):
         m, n = A.shape
         k = min(m, n)

@@ -53,6 +53,8 @@ struct mpsk_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* ws2 = nullptr;
   size_t ws2_bytes = 0;
+  void* ws3 = nullptr;          // transposed operands of mpsk_qrlq_pair
+  size_t ws3_bytes = 0;
   int* h_flags = nullptr;       // pinned [2]
   std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
 };
@@ -99,6 +101,7 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->d_flag) (void)hipFree(c->d_flag);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->ws2) (void)hipFree(c->ws2);
+  if (c->ws3) (void)hipFree(c->ws3);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -596,6 +599,34 @@ int mpsk_qrpos2(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1, i
     e2 = qrpos(m, n, (const double*)As[t], ldas[t], (double*)Qs[t], ldqs[t], (double*)Rs[t], ldrs[t], (double*)c->ws, c->stream, &err);
     if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (pair) failed");
   }
+  return MPSK_OK;
+}
+
+// QRpos of A1 (m x n) and LQpos of A2 (n x m) in flight together: the left-moving DMRG site update needs
+// leftorth of the OLD AC (galerkin projector) and rightorth of the NEW AC (next site's AR / C) at the same moment;
+// for Dl == Dr the transposed tail of the new AC has the shape of the old AC's front matrix.
+int mpsk_qrlq_pair(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1, int ldq1, void* R1, int ldr1,
+                   const void* A2, int lda2, void* L2, int ldl2, void* Q2, int ldq2) {
+  REQUIRE(c && A1 && Q1 && R1 && A2 && L2 && Q2, "NULL argument");
+  REQUIRE(m >= n && n > 0, "needs m >= n > 0");
+  REQUIRE(lda1 >= m && ldq1 >= m && ldr1 >= n && lda2 >= n && ldl2 >= n && ldq2 >= n, "leading dimension too small");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t need = sizeof(double) * ((size_t)2 * m * n + (size_t)n * n + 8);
+  if (c->ws3_bytes < need) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    if (c->ws3) HIPCHK(hipFree(c->ws3));
+    c->ws3 = nullptr; c->ws3_bytes = 0;
+    if (hipMalloc(&c->ws3, need) != hipSuccess) return fail(MPSK_ERR_NOMEM, "mpsk_qrlq_pair: workspace hipMalloc failed");
+    c->ws3_bytes = need;
+  }
+  double* At = (double*)c->ws3;                                 // m x n  (= A2^T)
+  double* Qt = At + (((size_t)m * n + 1) & ~(size_t)1);         // m x n
+  double* Rt = Qt + (((size_t)m * n + 1) & ~(size_t)1);         // n x n
+  HIPCHK(transpose((const double*)A2, lda2, n, m, At, m, c->stream));
+  if (int rc = mpsk_qrpos2(c, m, n, A1, lda1, Q1, ldq1, R1, ldr1, At, m, Qt, m, Rt, n)) return rc;
+  HIPCHK(transpose(Qt, m, m, n, (double*)Q2, ldq2, c->stream));
+  HIPCHK(transpose(Rt, n, n, n, (double*)L2, ldl2, c->stream));
   return MPSK_OK;
 }
 

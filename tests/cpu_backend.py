@@ -181,6 +181,12 @@ class CpuBackend:
         q2, r2 = self.qrpos(A2)
         return q1, r1, q2, r2
 
+    def qrlq_pair(self, A1, A2):
+        self._count("qrlq_pair")
+        q1, r1 = self.qrpos(A1)
+        l2, q2 = self.lqpos(A2)
+        return q1, r1, l2, q2
+
     def lqpos(self, A):
         self._count("lqpos")
         l, q = mo.lqpos(self.download(A))

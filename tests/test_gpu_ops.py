@@ -394,3 +394,18 @@ def test_abi_error_behaviour(be):
         be.dC(be.empty(3, 4, 4), be.empty(2, 5, 5), be.empty(4, 5))                 # level count mismatch
     Qg, Rg = be.qrpos(A)                                                            # context still fine
     assert relerr(be.download(Qg) @ be.download(Rg), be.download(A)) < 1e-13
+
+
+@pytest.mark.parametrize("m,n", [(8, 4), (768, 384), (2048, 1024)])
+def test_qrlq_pair(be, m, n):
+    """mpsk_qrlq_pair == mpsk_qrpos of the first + mpsk_lqpos of the second operand."""
+    rng = np.random.default_rng(3 * m + n)
+    A1, A2 = rng.random((m, n)), rng.standard_normal((n, m))
+    Q1, R1, L2, Q2 = (be.download(t) for t in be.qrlq_pair(be.upload(A1), be.upload(A2)))
+    assert np.abs(Q1.T @ Q1 - np.eye(n)).max() < 1e-12 and relerr(Q1 @ R1, A1) < 1e-12
+    assert np.abs(Q2 @ Q2.T - np.eye(n)).max() < 1e-12 and relerr(L2 @ Q2, A2) < 1e-12
+    assert np.all(np.diag(R1) > 0) and np.all(np.diag(L2) > 0)
+    assert np.abs(np.tril(R1, -1)).max() == 0.0 and np.abs(np.triu(L2, 1)).max() == 0.0
+    Qs, Rs = (be.download(t) for t in be.qrpos(be.upload(A1)))
+    Ls, Qls = (be.download(t) for t in be.lqpos(be.upload(A2)))
+    assert relerr(Q1, Qs) < 1e-12 and relerr(L2, Ls) < 1e-11 and relerr(Q2, Qls) < 1e-10
