@@ -140,6 +140,12 @@ def _log(alg, name, it, E, eps, t0):
         print(f"[ Info: {name} {it:3d}:\tobj = {E:+.12e}\terr = {eps:.10e}\ttime = {time.time() - t0:.2f} sec", flush=True)
 
 
+def _no_cplx(psi, what):
+    if getattr(psi, "cplx", False):
+        raise NotImplementedError(f"{what} on a complex (embedded) state: tsvd of the embedding defines singular vectors "
+                                  "only up to a rotation inside each doubled singular value (cplx.py)")
+
+
 def find_groundstate(psi, H, alg=None, envs=None):
     """find_groundstate(psi, H, alg[, envs]) -> (psi, envs, eps)  (find_groundstate.jl:19-41)."""
     if alg is None:
@@ -147,6 +153,7 @@ def find_groundstate(psi, H, alg=None, envs=None):
     if isinstance(alg, DMRG):
         return _dmrg(psi.copy(), H, alg, envs)
     if isinstance(alg, DMRG2):
+        _no_cplx(psi, "DMRG2")
         return _dmrg2(psi.copy(), H, alg, envs)
     if isinstance(alg, VUMPS):
         return _vumps(psi, H, alg, envs)
@@ -351,29 +358,46 @@ class TDVP2:  # tdvp.jl:105-111 ; trscheme = truncerr(1e-3)
     finalize: object = None
 
 
-def integrate(be, f, y0, t, dt, alg, ws=None):
+def integrate(be, f, y0, t, dt, alg, ws=None, cplx=False):
     """integrate(f, y0, t, dt, Lanczos)  (integrators.jl:20-25): y = exp(-im*dt*f) y0.
-    The HIP path computes in real fp64, so only steps with real -im*dt are accepted here
-    (imaginary-time evolution dt = -1j*tau); real-time steps need the complex128 build."""
+    Real states: only steps with real -im*dt (imaginary time, dt = -1j*tau) keep the tensors real.
+    Embedded complex states (cplx.py): any complex dt;  exp(z f) with z = -im*dt = zr + i zi is the exponential of
+    the real generator  x -> zr f(x) + zi (i f(x))  on the embedded tensors (general Arnoldi)."""
     z = -1j * complex(dt)
-    if abs(z.imag) > 0.0:
-        raise NotImplementedError("real-time evolution needs complex128 tensors (MPSK_C128 is not built yet); "
-                                  "pass dt = -1j*tau for imaginary-time evolution")
-    y, _ = krylov.exponentiate(be, f, z.real, y0, tol=alg.tol, krylovdim=alg.krylovdim, maxiter=alg.maxiter, ws=ws)
+    if not cplx:
+        if abs(z.imag) > 0.0:
+            raise NotImplementedError("real-time evolution of a REAL state leaves the reals: build the state from "
+                                      "complex tensors (FiniteMPS(..., dtype=complex)) or pass dt = -1j*tau")
+        y, _ = krylov.exponentiate(be, f, z.real, y0, tol=alg.tol, krylovdim=alg.krylovdim, maxiter=alg.maxiter, ws=ws)
+        return y
+    if z.imag == 0.0:
+        y, _ = krylov.exponentiate(be, f, z.real, y0, tol=alg.tol, krylovdim=alg.krylovdim, maxiter=alg.maxiter, ws=ws)
+        return y
+    from .cplx import times_i
+    tmp = be.empty(*y0.shape)
+
+    def gen(x, out):
+        f(x, tmp)
+        times_i(be, tmp, out)                 # out = i f(x)
+        be.axpby(z.real, tmp, z.imag, out)    # out = zr f(x) + zi (i f(x))
+        return out
+
+    y, _ = krylov.exponentiate_general(be, gen, y0, tol=alg.tol, krylovdim=alg.krylovdim, maxiter=alg.maxiter, ws=ws)
     return y
 
 
 def _timestep_tdvp(psi, H, t, dt, alg: TDVP, envs):  # tdvp.jl:61-94
     be, L = psi.be, len(psi)
     ws = krylov.KrylovWorkspace(be)
+    cx = getattr(psi, "cplx", False)
     for i in range(L - 1):
-        psi.set_AC(i, integrate(be, ddAC(i, psi, H, envs), psi.AC(i), t, dt / 2, alg, ws))
-        psi.set_CR(i, integrate(be, ddC(i, psi, H, envs), psi.CR(i), t, -dt / 2, alg, ws))
-    psi.set_AC(L - 1, integrate(be, ddAC(L - 1, psi, H, envs), psi.AC(L - 1), t, dt / 2, alg, ws))
+        psi.set_AC(i, integrate(be, ddAC(i, psi, H, envs), psi.AC(i), t, dt / 2, alg, ws, cx))
+        psi.set_CR(i, integrate(be, ddC(i, psi, H, envs), psi.CR(i), t, -dt / 2, alg, ws, cx))
+    psi.set_AC(L - 1, integrate(be, ddAC(L - 1, psi, H, envs), psi.AC(L - 1), t, dt / 2, alg, ws, cx))
     for i in range(L - 1, 0, -1):
-        psi.set_AC(i, integrate(be, ddAC(i, psi, H, envs), psi.AC(i), t + dt / 2, dt / 2, alg, ws))
-        psi.set_CR(i - 1, integrate(be, ddC(i - 1, psi, H, envs), psi.CR(i - 1), t + dt / 2, -dt / 2, alg, ws))
-    psi.set_AC(0, integrate(be, ddAC(0, psi, H, envs), psi.AC(0), t + dt / 2, dt / 2, alg, ws))
+        psi.set_AC(i, integrate(be, ddAC(i, psi, H, envs), psi.AC(i), t + dt / 2, dt / 2, alg, ws, cx))
+        psi.set_CR(i - 1, integrate(be, ddC(i - 1, psi, H, envs), psi.CR(i - 1), t + dt / 2, -dt / 2, alg, ws, cx))
+    psi.set_AC(0, integrate(be, ddAC(0, psi, H, envs), psi.AC(0), t + dt / 2, dt / 2, alg, ws, cx))
     return psi, envs
 
 
@@ -433,6 +457,7 @@ def timestep(psi, H, t, dt, alg=None, envs=None):
     psi = psi.copy()
     envs = environments(psi, H) if envs is None else envs
     if isinstance(alg, TDVP2):
+        _no_cplx(psi, "TDVP2")
         return _timestep_tdvp2(psi, H, t, dt, alg, envs)
     return _timestep_tdvp(psi, H, t, dt, alg, envs)
 

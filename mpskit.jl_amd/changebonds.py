@@ -131,6 +131,8 @@ def changebonds(psi, H=None, alg=None, envs=None, rng=None):
         H, alg = None, H
     if not isinstance(psi, FiniteMPS):
         raise NotImplementedError("changebonds is built for FiniteMPS (optimalexpand.jl:72-102, svdcut.jl:14-23)")
+    if getattr(psi, "cplx", False):
+        raise NotImplementedError("changebonds on a complex (embedded) state needs tsvd of the embedding (cplx.py)")
     psi = psi.copy()
     if isinstance(alg, SvdCut):
         out = _svd_cut(psi, alg)

@@ -167,6 +167,53 @@ def exponentiate(be: Backend, matvec, z: float, x0: DTensor, tol=1e-12, krylovdi
     return out, nmv
 
 
+def exponentiate_general(be: Backend, gen, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
+                         ws: KrylovWorkspace | None = None):
+    """y = exp(G) x0 for a general real linear generator gen(x, out) -> out (Arnoldi; the small exp of the
+    Hessenberg matrix on the host).  Used for complex time steps on embedded tensors, where
+    G = Im(dt) H + Re(dt) (-i H) is neither symmetric nor antisymmetric.  Same a-posteriori estimate and
+    step-cutting as `exponentiate`.  Returns (y, n_matvecs)."""
+    from scipy.linalg import expm
+    ws = KrylovWorkspace(be) if ws is None else ws
+    shape = x0.shape
+    vecs = ws.get(shape, krylovdim + 2)
+    V, cur = vecs[:krylovdim + 1], vecs[krylovdim + 1]
+    be.axpby(1.0, x0, 0.0, cur)
+    remaining, nmv = 1.0, 0
+    for _ in range(maxiter):
+        nrm = be.norm(cur)
+        if nrm == 0.0 or remaining <= 0.0:
+            break
+        be.axpby(1.0 / nrm, cur, 0.0, V[0])
+        Hm = np.zeros((krylovdim + 1, krylovdim))
+        k, s, u = 0, remaining, None
+        while k < krylovdim:
+            w = V[k + 1]
+            gen(V[k], w)
+            nmv += 1
+            h, beta = be.orth_step(V[:k + 1], w)
+            Hm[:k + 1, k] = h
+            Hm[k + 1, k] = beta
+            k += 1
+            u = expm(remaining * Hm[:k, :k])[:, 0]
+            if beta * abs(u[-1]) <= tol * max(remaining, 1e-300) or beta < 1e-300:
+                s = remaining
+                break
+            if k == krylovdim:
+                s = remaining
+                while True:
+                    u = expm(s * Hm[:k, :k])[:, 0]
+                    if beta * abs(u[-1]) <= tol * s or s < 1e-12:
+                        break
+                    s *= 0.5
+                break
+        be.lincomb(V[:k], nrm * u, out=cur)
+        remaining -= s
+    out = be.empty(*shape)
+    be.axpby(1.0, cur, 0.0, out)
+    return out, nmv
+
+
 def gmres(be: Backend, matvec, b: DTensor, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
           ws: KrylovWorkspace | None = None):
     """Restarted GMRES for matvec(x) = b on device vectors (KrylovKit.linsolve stand-in,

@@ -55,6 +55,13 @@ class FiniteMPS:
         As: list of host arrays (Dl, d, Dr) or DTensors."""
         self.be = default_backend() if be is None else be
         be = self.be
+        # complex128 input: carried as the real 2x2 embedding on the bond indices (cplx.py); the embedded
+        # Frobenius norm is sqrt(2) times the complex one
+        self.cplx = any((not isinstance(a, DTensor)) and np.iscomplexobj(a) for a in As)
+        if self.cplx:
+            from .cplx import embed
+            As = [embed(np.asarray(a)) for a in As]
+        nrm_target = np.sqrt(2.0) if self.cplx else 1.0
         As = [a if isinstance(a, DTensor) else be.upload(np.asarray(a)) for a in As]
         N = len(As)
         C = None
@@ -63,7 +70,7 @@ class FiniteMPS:
                 As[i] = mul_CA(be, C, As[i])
             As[i], C = leftorth(be, As[i])
             if normalize:
-                be.scal(1.0 / be.norm(C), C)
+                be.scal(nrm_target / be.norm(C), C)
         self.N = N
         self.ALs = list(As)
         self.ARs = [None] * N
@@ -72,7 +79,7 @@ class FiniteMPS:
         self.CLs[N] = C
 
     @classmethod
-    def random(cls, L, d, D, rng, normalize=True, be=None):
+    def random(cls, L, d, D, rng, normalize=True, be=None, dtype=None):
         """FiniteMPS(rand, elt, L, P, maxV): bond dims min(d^i, D, d^(L-i)) (finitemps.jl:171-207),
         entries uniform[0,1)."""
         dims = [1]
@@ -81,11 +88,14 @@ class FiniteMPS:
         dims.append(1)
         for k in range(L - 1, 0, -1):
             dims[k] = min(dims[k], dims[k + 1] * d)
+        if dtype is not None and np.issubdtype(dtype, np.complexfloating):
+            return cls([rng.random((dims[i], d, dims[i + 1])) + 1j * rng.random((dims[i], d, dims[i + 1]))
+                        for i in range(L)], normalize=normalize, be=be)
         return cls([rng.random((dims[i], d, dims[i + 1])) for i in range(L)], normalize=normalize, be=be)
 
     def copy(self):
         o = object.__new__(FiniteMPS)
-        o.be, o.N = self.be, self.N
+        o.be, o.N, o.cplx = self.be, self.N, self.cplx
         o.ALs, o.ARs, o.ACs, o.CLs = list(self.ALs), list(self.ARs), list(self.ACs), list(self.CLs)
         return o
 
@@ -203,13 +213,22 @@ class FiniteMPS:
         return al_old
 
     def norm(self):  # finitemps.jl:467
-        return self.be.norm(self.AC(0))
+        n = self.be.norm(self.AC(0))
+        return n / np.sqrt(2.0) if self.cplx else n
+
+    def download(self, t):
+        """host copy of one of this state's tensors (complex if the state is complex: un-embedded)."""
+        h = self.be.download(t)
+        if self.cplx:
+            from .cplx import extract
+            return extract(h)
+        return h
 
     def bond_dims(self):
         out = []
         for i in range(self.N):
             t = self.ALs[i] or self.ARs[i] or self.ACs[i]
-            out.append(t.shape[2])
+            out.append(t.shape[2] // 2 if self.cplx else t.shape[2])
         return out
 
     def to_host(self):

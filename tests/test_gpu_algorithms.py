@@ -346,3 +346,41 @@ def test_idmrg1_reference_recorded_energy(be):
     p2, e2, eps2 = mk.find_groundstate(mk.InfiniteMPS.from_tensors([B, B.copy()], be=be), H, mk.IDMRG1(tol=1e-10, maxiter=300))
     E2 = mk.expectation_value(p2, H, e2)
     assert eps2 < 1e-10 and abs(float(np.sum(E2)) / 2 - (-1.0635444099)) < 1e-8
+
+
+def test_complex_states_realtime_tdvp_and_dmrg(be):
+    """complex128 through the fp64 kernels (cplx.py: 2x2 real blocks on the bond indices).  test/algorithms.jl:96-110
+    (real-time TDVP conserves the energy) + parity with the oracle's complex arithmetic: canonical form, expectation
+    values, the tensors after a real-time / mixed TDVP step, 1-site DMRG energy; D large enough for CholeskyQR."""
+    mk = _mk()
+    from mpskit_jl_amd import cplx
+    rng = np.random.default_rng(23)
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)
+    for L, D in ((6, 4), (10, 48)):
+        dims = mo.FiniteMPS.random(L, 2, D, np.random.default_rng(0)).bond_dims()
+        shp = [(1 if i == 0 else dims[i - 1], 2, dims[i]) for i in range(L)]
+        As = [rng.random(s) - 0.5 + 1j * (rng.random(s) - 0.5) for s in shp]
+        pg, po = mk.FiniteMPS(As, normalize=True, be=be), mo.FiniteMPS(As, normalize=True)
+        assert pg.cplx and pg.bond_dims() == po.bond_dims() and abs(pg.norm() - 1) < 1e-13
+        for i in (0, L // 2, L - 1):
+            for gt, ot in ((pg.AC(i), po.AC(i)), (pg.AR(i), po.AR(i)), (pg.AL(i), po.AL(i))):
+                assert cplx.structure_defect(be.download(gt)) < 1e-12
+                assert np.abs(pg.download(gt) - ot).max() < 1e-11
+        eg, eo = mk.FinEnv(pg, Hg), mo.FinEnv(po, Ho)
+        Eo = mo.expectation_value(po, Ho, eo)
+        assert np.abs(mk.expectation_value(pg, Hg, eg) - Eo.real).max() < 1e-11
+        p1, e1 = mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP())
+        q1, f1 = mo.tdvp_timestep(po, Ho, 0.0, 0.1)
+        for i in (0, L // 2, L - 1):
+            assert np.abs(p1.download(p1.AC(i)) - q1.AC(i)).max() < 1e-9
+        assert abs(p1.norm() - 1) < 1e-11
+        assert abs(np.sum(mk.expectation_value(p1, Hg, e1)) - np.sum(Eo).real) < 1e-7 * max(1.0, abs(np.sum(Eo).real))
+    p2, _ = mk.timestep(pg, Hg, 0.0, 0.05 - 0.02j, mk.TDVP())
+    q2, _ = mo.tdvp_timestep(po, Ho, 0.0, 0.05 - 0.02j)
+    assert np.abs(p2.download(p2.AC(4)) - q2.AC(4)).max() < 1e-9
+    p3, e3, eps = mk.find_groundstate(pg, Hg, mk.DMRG(tol=1e-9, maxiter=6))
+    _, _, epso, logo = mo.dmrg(po, Ho, tol=1e-9, maxiter=6)
+    E3 = float(np.sum(mk.expectation_value(p3, Hg, e3)))
+    assert abs(E3 - logo[-1][1]) <= 1e-9 * abs(E3)
+    with pytest.raises(NotImplementedError):
+        mk.find_groundstate(pg, Hg, mk.DMRG2())

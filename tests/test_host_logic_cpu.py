@@ -169,3 +169,44 @@ def test_lazysum_matches_summed_hamiltonian(cb):
     H2 = mk.LazySum([Hfull, Hfull], [0.25, 0.75])
     y2 = cb.download(mk.ddAC(2, pg, H2, mk.environments(pg, H2))(x))
     assert np.abs(y2 - yf).max() < 1e-12 * max(1.0, np.abs(yf).max())
+
+
+def test_complex_states_by_bond_embedding(cb):
+    """cplx.py: complex128 FiniteMPS carried as real 2x2 blocks on the bond indices.  The lazy gauge (QRpos / LQpos),
+    the environments, expectation values, 1-site DMRG and a REAL-TIME TDVP step on the embedded tensors reproduce
+    the oracle's complex arithmetic (the reference's default scalar type)."""
+    from mpskit_jl_amd import cplx
+    rng = np.random.default_rng(23)
+    L, D = 6, 4
+    dims = mo.FiniteMPS.random(L, 2, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.random((1 if i == 0 else dims[i - 1], 2, dims[i])) + 1j * rng.random((1 if i == 0 else dims[i - 1], 2, dims[i]))
+          for i in range(L)]
+    M1, M2 = rng.random((3, 4)) + 1j * rng.random((3, 4)), rng.random((4, 5)) + 1j * rng.random((4, 5))
+    assert np.abs(cplx.extract(cplx.embed(M1) @ cplx.embed(M2)) - M1 @ M2).max() < 1e-14
+    assert np.abs(cplx.embed(M1).T - cplx.embed(M1.conj().T)).max() == 0.0
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=cb), mo.heisenberg_mpo(0.5)
+    pg, po = mk.FiniteMPS(As, normalize=True, be=cb), mo.FiniteMPS(As, normalize=True)
+    assert pg.cplx and pg.bond_dims() == po.bond_dims() and abs(pg.norm() - 1) < 1e-13
+    for i in range(L):                                   # same canonical form, structure kept by QRpos / LQpos
+        for gt, ot in ((pg.AC(i), po.AC(i)), (pg.AR(i), po.AR(i)), (pg.AL(i), po.AL(i))):
+            assert cplx.structure_defect(cb.download(gt)) < 1e-13
+            assert np.abs(pg.download(gt) - ot).max() < 1e-12
+    eg, eo = mk.FinEnv(pg, Hg), mo.FinEnv(po, Ho)
+    Eg, Eo = mk.expectation_value(pg, Hg, eg), mo.expectation_value(po, Ho, eo)
+    assert np.abs(Eg - Eo.real).max() < 1e-12
+    # real-time TDVP step: tensors, norm and energy
+    p1, e1 = mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP())
+    q1, f1 = mo.tdvp_timestep(po, Ho, 0.0, 0.1)
+    for i in range(L):
+        assert np.abs(p1.download(p1.AC(i)) - q1.AC(i)).max() < 1e-10
+    assert abs(p1.norm() - 1) < 1e-12
+    assert abs(np.sum(mk.expectation_value(p1, Hg, e1)) - np.sum(Eo).real) < 1e-8      # energy conserved
+    # mixed complex step and 1-site DMRG on the complex state
+    p2, _ = mk.timestep(pg, Hg, 0.0, 0.05 - 0.02j, mk.TDVP())
+    q2, _ = mo.tdvp_timestep(po, Ho, 0.0, 0.05 - 0.02j)
+    assert np.abs(p2.download(p2.AC(2)) - q2.AC(2)).max() < 1e-10
+    p3, e3, eps = mk.find_groundstate(pg, Hg, mk.DMRG(tol=1e-10, maxiter=8))
+    _, _, epso, logo = mo.dmrg(po, Ho, tol=1e-10, maxiter=8)
+    assert abs(np.sum(mk.expectation_value(p3, Hg, e3)) - logo[-1][1]) < 1e-10 * abs(logo[-1][1])
+    with pytest.raises(NotImplementedError):
+        mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP2())
