@@ -10,8 +10,8 @@ matrix are the embeddings of the complex QRpos / LQpos (the embedded R is upper 
 diagonal and the factorization is unique); a Krylov solver started from an embedded tensor stays in the embedded
 subspace.  Cost: 8x the real flops (a native complex kernel needs 4x) and 4x the memory -- the price of reusing
 the fp64 MFMA path of this round unchanged (DESIGN.md section 7 has the native plan).  The chain's boundary bond
-dimension becomes 2.  Supported: FiniteMPS with 1-site algorithms (DMRG, TDVP incl. real time, calc_galerkin,
-expectation_value) and real MPO Hamiltonians; tsvd-based 2-site algorithms are not (singular vectors of the
+dimension becomes 2.  Supported: FiniteMPS / InfiniteMPS with 1-site algorithms (DMRG, VUMPS, TDVP incl. real time,
+calc_galerkin, expectation_value) and real MPO Hamiltonians; tsvd-based 2-site algorithms are not (singular vectors of the
 embedding are only defined up to a rotation inside each doubled singular value)."""
 from __future__ import annotations
 

@@ -328,12 +328,18 @@ class InfiniteMPS:
     def from_tensors(cls, A, tol=1e-14, maxiter=100, be=None):
         """infinitemps.jl:139-170 (gaugefix! order = :LR)."""
         be = default_backend() if be is None else be
+        cx = any((not isinstance(a, DTensor)) and np.iscomplexobj(a) for a in A)
+        if cx:                                 # complex128 via the bond embedding (cplx.py)
+            from .cplx import embed
+            A = [embed(np.asarray(a)) for a in A]
         A = [a if isinstance(a, DTensor) else be.upload(np.asarray(a)) for a in A]
         D = A[0].shape[0]
         AL, CR = uniform_leftorth(be, A, be.upload(np.eye(D)), tol, maxiter)
         AR, CR = uniform_rightorth(be, AL, CR[-1], tol, maxiter)
         AC = [mul_AC(be, AL[i], CR[i]) for i in range(len(A))]
-        return cls(AL, AR, CR, AC, be)
+        out = cls(AL, AR, CR, AC, be)
+        out.cplx = cx
+        return out
 
     @classmethod
     def from_AL(cls, AL, C0, tol=1e-14, maxiter=100, be=None):

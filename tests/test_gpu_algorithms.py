@@ -384,3 +384,17 @@ def test_complex_states_realtime_tdvp_and_dmrg(be):
     assert abs(E3 - logo[-1][1]) <= 1e-9 * abs(E3)
     with pytest.raises(NotImplementedError):
         mk.find_groundstate(pg, Hg, mk.DMRG2())
+
+
+def test_complex_infinite_mps_vumps(be):
+    """complex128 InfiniteMPS through the bond embedding: uniform gauge vs the oracle's complex AL, VUMPS energy vs the
+    value recorded in the reference docs."""
+    mk = _mk()
+    from mpskit_jl_amd import cplx
+    rng = np.random.default_rng(4)
+    A = rng.random((10, 2, 10)) + 1j * rng.random((10, 2, 10))
+    H = mk.transverse_field_ising(1.0, 0.5, be=be)
+    psi, po = mk.InfiniteMPS.from_tensors([A], be=be), mo.InfiniteMPS.from_tensors([A])
+    assert psi.cplx and np.abs(cplx.extract(be.download(psi.AL[0])) - po.AL[0]).max() < 1e-11
+    p, e, eps = mk.find_groundstate(psi, H, mk.VUMPS(tol=1e-10, maxiter=60))
+    assert eps < 1e-9 and abs(float(np.sum(mk.expectation_value(p, H, e))) - (-1.063544409973)) < 5e-12

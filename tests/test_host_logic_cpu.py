@@ -210,3 +210,18 @@ def test_complex_states_by_bond_embedding(cb):
     assert abs(np.sum(mk.expectation_value(p3, Hg, e3)) - logo[-1][1]) < 1e-10 * abs(logo[-1][1])
     with pytest.raises(NotImplementedError):
         mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP2())
+
+
+def test_complex_infinite_mps_vumps(cb):
+    """complex128 InfiniteMPS via the bond embedding: uniform gauge (AL equals the oracle's complex AL; C only up to the
+    gauge phase of the fixed point) and VUMPS energy."""
+    from mpskit_jl_amd import cplx
+    rng = np.random.default_rng(4)
+    A = rng.random((6, 2, 6)) + 1j * rng.random((6, 2, 6))
+    H, Ho = mk.transverse_field_ising(1.0, 0.5, be=cb), mo.tfi_mpo(1.0, 0.5)
+    psi, po = mk.InfiniteMPS.from_tensors([A], be=cb), mo.InfiniteMPS.from_tensors([A])
+    assert psi.cplx and cplx.structure_defect(cb.download(psi.AL[0])) < 1e-13
+    assert np.abs(cplx.extract(cb.download(psi.AL[0])) - po.AL[0]).max() < 1e-12
+    p, e, eps = mk.find_groundstate(psi, H, mk.VUMPS(tol=1e-10, maxiter=60))
+    _, _, _, logo = mo.vumps(po, Ho, tol=1e-10, maxiter=60)
+    assert eps < 1e-9 and abs(float(np.sum(mk.expectation_value(p, H, e))) - logo[-1][1]) < 1e-10
