@@ -159,6 +159,10 @@ int mpsk_vdot(mpsk_ctx* ctx, int64_t n, const void* x, const void* y, double* ho
 int mpsk_vnrm2(mpsk_ctx* ctx, int64_t n, const void* x, double* host_out);
 int mpsk_vaxpby(mpsk_ctx* ctx, int64_t n, double alpha, const void* x, double beta, void* y);
 int mpsk_vscal(mpsk_ctx* ctx, int64_t n, double alpha, void* x);
+/* y = (I (x) J) x, J = [[0,-1],[1,0]], on interleaved row pairs of a tensor whose first dimension is even: the
+ * multiplication by i of a complex tensor carried as 2x2 real blocks on its bond indices (integrators.jl:21
+ * `-1im * dt` on the embedded representation, mpskit.jl_amd/cplx.py) */
+int mpsk_vtimes_i(mpsk_ctx* ctx, int64_t n, const void* x, void* y);
 int mpsk_vcopy(mpsk_ctx* ctx, int64_t n, const void* x, void* y);
 int mpsk_vzero(mpsk_ctx* ctx, int64_t n, void* x);
 /* fused Gram-Schmidt helpers: xs = HOST array of k device pointers.

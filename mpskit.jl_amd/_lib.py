@@ -73,6 +73,7 @@ SIGNATURES = {
     "mpsk_vnrm2": [C.c_void_p, C.c_int64, C.c_void_p, c_double_p],
     "mpsk_vaxpby": [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_double, C.c_void_p],
     "mpsk_vscal": [C.c_void_p, C.c_int64, C.c_double, C.c_void_p],
+    "mpsk_vtimes_i": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "mpsk_vcopy": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "mpsk_vzero": [C.c_void_p, C.c_int64, C.c_void_p],
     "mpsk_vmultidot": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p],

@@ -300,6 +300,12 @@ class Backend:
         check(self.lib.mpsk_vaxpby(self.ctx, x.size, float(alpha), x.ptr, float(beta), y.ptr), "mpsk_vaxpby")
         return y
 
+    def times_i(self, x: DTensor, out: DTensor = None):
+        """embedded complex tensors (cplx.py): out = i * x  (first dimension = interleaved re/im rows)."""
+        y = self.empty(*x.shape) if out is None else out
+        check(self.lib.mpsk_vtimes_i(self.ctx, x.size, x.ptr, y.ptr), "mpsk_vtimes_i")
+        return y
+
     def scal(self, alpha, x: DTensor):
         check(self.lib.mpsk_vscal(self.ctx, x.size, float(alpha), x.ptr), "mpsk_vscal")
         return x

@@ -46,16 +46,7 @@ def structure_defect(E):
                np.abs(E[0::2, ..., 1::2] + E[1::2, ..., 0::2]).max(initial=0.0))
 
 
-_J_CACHE = {}
-
-
 def times_i(be, x: DTensor, out: DTensor = None):
-    """emb(i * z) = (I_Dl (x) J) . emb(z) with J = [[0, -1], [1, 0]] acting on the first (left bond) index."""
-    n = x.shape[0]
-    key = (id(be), n)
-    if key not in _J_CACHE:
-        _J_CACHE[key] = be.upload(np.kron(np.eye(n // 2), np.array([[0.0, -1.0], [1.0, 0.0]])))
-    rest = x.size // n
-    y = be.empty(*x.shape) if out is None else out
-    be.gemm(_J_CACHE[key], x.reshape(n, rest), out=y.reshape(n, rest))
-    return y
+    """emb(i * z) = (I_Dl (x) J) . emb(z) with J = [[0, -1], [1, 0]] acting on the first (left bond) index:
+    rows (2a, 2a+1) -> (-row 2a+1, row 2a)  (mpsk_vtimes_i)."""
+    return be.times_i(x, out)

@@ -806,6 +806,14 @@ int mpsk_vscal(mpsk_ctx* c, int64_t n, double alpha, void* x) {
   HIPCHK(vec_scal(alpha, (double*)x, n, c->stream));
   return MPSK_OK;
 }
+int mpsk_vtimes_i(mpsk_ctx* c, int64_t n, const void* x, void* y) {
+  REQUIRE(c && x && y, "NULL argument");
+  REQUIRE(n % 2 == 0 && x != y, "needs an even length (interleaved re/im row pairs) and out-of-place operands");
+  REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "operands must be 16-byte aligned");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(vec_times_i((const double*)x, (double*)y, n, c->stream));
+  return MPSK_OK;
+}
 int mpsk_vcopy(mpsk_ctx* c, int64_t n, const void* x, void* y) {
   REQUIRE(c && x && y, "NULL argument");
   HIPCHK(hipMemcpyAsync(y, x, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));

@@ -74,6 +74,7 @@ constexpr int MPSK_DOT_SCRATCH = 8 * 1024;
 hipError_t vec_multidot(const double* const* xs, int k, const double* y, int64_t n, double* d_out,
                         double* d_partial, hipStream_t s);
 hipError_t vec_axpby(double a, const double* x, double b, double* y, int64_t n, hipStream_t s);
+hipError_t vec_times_i(const double* x, double* y, int64_t n, hipStream_t s);
 hipError_t vec_scal(double a, double* x, int64_t n, hipStream_t s);
 hipError_t vec_scal_rsqrt_dev(const double* d_n2, double* x, int64_t n, hipStream_t s);
 hipError_t vec_multiaxpy(const double* const* xs, const double* d_coefs, int k, double sign, double* y,

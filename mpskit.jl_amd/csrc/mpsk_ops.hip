@@ -225,6 +225,25 @@ __global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __re
     y[n - 1] = (b == 0.0) ? a * x[n - 1] : a * x[n - 1] + b * y[n - 1];
 }
 
+// y = (I (x) J) x on interleaved row pairs, J = [[0, -1], [1, 0]]:  y[2a] = -x[2a+1], y[2a+1] = x[2a]  (every column;
+// the leading dimension is even, so the flat buffer is a sequence of (re-row, im-row) pairs).  This is "times i" for
+// complex tensors carried as 2x2 real blocks on the bond indices (mpskit.jl_amd/cplx.py).
+__global__ __launch_bounds__(256) void times_i_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t npairs) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < npairs; e += (int64_t)gridDim.x * blockDim.x) {
+    const d2 v = reinterpret_cast<const d2*>(x)[e];
+    reinterpret_cast<d2*>(y)[e] = d2{-v.y, v.x};
+  }
+}
+hipError_t vec_times_i(const double* x, double* y, int64_t n, hipStream_t s) {
+  const int64_t npairs = n / 2;
+  int64_t nb = (npairs + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(times_i_kernel, dim3((int)nb), dim3(256), 0, s, x, y, npairs);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void scal_kernel(double a, double* x, int64_t n) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     x[e] *= a;

@@ -210,6 +210,12 @@ class CpuBackend:
         y.buf[: y.size] = torch.from_numpy(np.ascontiguousarray(v))
         return y
 
+    def times_i(self, x, out=None):
+        v = self._v(x).reshape(-1, 2)
+        y = self.empty(*x.shape) if out is None else out
+        self._v(y)[:] = np.stack([-v[:, 1], v[:, 0]], axis=1).reshape(-1)
+        return y
+
     def scal(self, alpha, x):
         x.buf[: x.size] *= alpha
         return x
