@@ -153,7 +153,6 @@ def find_groundstate(psi, H, alg=None, envs=None):
     if isinstance(alg, DMRG):
         return _dmrg(psi.copy(), H, alg, envs)
     if isinstance(alg, DMRG2):
-        _no_cplx(psi, "DMRG2")
         return _dmrg2(psi.copy(), H, alg, envs)
     if isinstance(alg, VUMPS):
         return _vumps(psi, H, alg, envs)
@@ -242,6 +241,18 @@ def _dmrg2(psi, H, alg: DMRG2, envs=None):  # dmrg.jl:80-137
         h = ddAC2(pos, psi, H, envs)
         _, new = fixedpoint(be, h, ac2, alg.eigalg, ws)
         Dl, d1, Dr, d2 = new.shape
+        if getattr(psi, "cplx", False):                       # complex state: structured split of the embedding
+            from .cplx import split_two_site
+            al, c, ar, _, _ = split_two_site(be, new, alg.trunc_dim, trunc_err)
+            be.scal(np.sqrt(2.0) / be.norm(c), c)             # normalize!(c) (embedded Frobenius norm = sqrt 2)
+            k = c.shape[0]
+            t = be.gemm(al.reshape(Dl * d1, k), c)
+            arm = be.empty(k, Dr * d2)
+            for s2 in range(d2):
+                be.copy2d(k, Dr, ar.ptr + 8 * s2 * k, k * d2, arm.ptr + 8 * s2 * k * Dr, k)
+            rec = be.gemm(t, arm)
+            v = be.dot(ac2, DTensor(rec.buf, ac2.shape)) / 2.0
+            return al, c, ar, abs(1 - abs(v))
         U, S, Vh, kept, _ = be.tsvd(new.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
         k = kept
         # normalize!(c)
@@ -401,9 +412,13 @@ def _timestep_tdvp(psi, H, t, dt, alg: TDVP, envs):  # tdvp.jl:61-94
     return psi, envs
 
 
-def _split_two_site(be, nac2, alg):
+def _split_two_site(be, nac2, alg, cx=False):
     """tsvd!(nac2; trunc) -> (al, c, ar) with ar[k, s2, b]   (tdvp.jl:124-126)."""
     Dl, d1, Dr, d2 = nac2.shape
+    if cx:
+        from .cplx import split_two_site
+        al, c, ar, _, _ = split_two_site(be, nac2, alg.trunc_dim, alg.trunc_err if alg.trunc_dim <= 0 else 0.0)
+        return al, c, ar
     trunc_err = alg.trunc_err if alg.trunc_dim <= 0 else 0.0
     U, S, Vh, k, _ = be.tsvd(nac2.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
     c = be.upload(np.diag(be.download(DTensor(S.buf, (k,)))))
@@ -418,20 +433,21 @@ def _split_two_site(be, nac2, alg):
 def _timestep_tdvp2(psi, H, t, dt, alg: TDVP2, envs):  # tdvp.jl:113-146
     be, L = psi.be, len(psi)
     ws = krylov.KrylovWorkspace(be)
+    cx = getattr(psi, "cplx", False)
     for i in range(L - 1):
         ac2 = _two_site_tensor(be, psi.AC(i), psi.AR(i + 1))
-        al, c, ar = _split_two_site(be, integrate(be, ddAC2(i, psi, H, envs), ac2, t, dt / 2, alg, ws), alg)
+        al, c, ar = _split_two_site(be, integrate(be, ddAC2(i, psi, H, envs), ac2, t, dt / 2, alg, ws, cx), alg, cx)
         psi.set_AC(i, (al, c))
         psi.set_AC(i + 1, (c, ar))
         if i != L - 2:
-            psi.set_AC(i + 1, integrate(be, ddAC(i + 1, psi, H, envs), psi.AC(i + 1), t, -dt / 2, alg, ws))
+            psi.set_AC(i + 1, integrate(be, ddAC(i + 1, psi, H, envs), psi.AC(i + 1), t, -dt / 2, alg, ws, cx))
     for i in range(L - 1, 0, -1):
         ac2 = _two_site_tensor(be, psi.AL(i - 1), psi.AC(i))
-        al, c, ar = _split_two_site(be, integrate(be, ddAC2(i - 1, psi, H, envs), ac2, t + dt / 2, dt / 2, alg, ws), alg)
+        al, c, ar = _split_two_site(be, integrate(be, ddAC2(i - 1, psi, H, envs), ac2, t + dt / 2, dt / 2, alg, ws, cx), alg, cx)
         psi.set_AC(i - 1, (al, c))
         psi.set_AC(i, (c, ar))
         if i != 1:
-            psi.set_AC(i - 1, integrate(be, ddAC(i - 1, psi, H, envs), psi.AC(i - 1), t + dt / 2, -dt / 2, alg, ws))
+            psi.set_AC(i - 1, integrate(be, ddAC(i - 1, psi, H, envs), psi.AC(i - 1), t + dt / 2, -dt / 2, alg, ws, cx))
     return psi, envs
 
 
@@ -457,7 +473,6 @@ def timestep(psi, H, t, dt, alg=None, envs=None):
     psi = psi.copy()
     envs = environments(psi, H) if envs is None else envs
     if isinstance(alg, TDVP2):
-        _no_cplx(psi, "TDVP2")
         return _timestep_tdvp2(psi, H, t, dt, alg, envs)
     return _timestep_tdvp(psi, H, t, dt, alg, envs)
 

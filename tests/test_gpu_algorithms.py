@@ -382,8 +382,6 @@ def test_complex_states_realtime_tdvp_and_dmrg(be):
     _, _, epso, logo = mo.dmrg(po, Ho, tol=1e-9, maxiter=6)
     E3 = float(np.sum(mk.expectation_value(p3, Hg, e3)))
     assert abs(E3 - logo[-1][1]) <= 1e-9 * abs(E3)
-    with pytest.raises(NotImplementedError):
-        mk.find_groundstate(pg, Hg, mk.DMRG2())
 
 
 def test_complex_infinite_mps_vumps(be):
@@ -398,3 +396,53 @@ def test_complex_infinite_mps_vumps(be):
     assert psi.cplx and np.abs(cplx.extract(be.download(psi.AL[0])) - po.AL[0]).max() < 1e-11
     p, e, eps = mk.find_groundstate(psi, H, mk.VUMPS(tol=1e-10, maxiter=60))
     assert eps < 1e-9 and abs(float(np.sum(mk.expectation_value(p, H, e))) - (-1.063544409973)) < 5e-12
+
+
+def _dense_state_c(psi):
+    """dense complex state vector of a complex (bond-embedded) FiniteMPS."""
+    L = len(psi)
+    vec = np.ones((1, 1), dtype=complex)
+    for i in range(L):
+        A = psi.download(psi.AL(i)) if i < L - 1 else psi.download(psi.AC(L - 1))
+        vec = np.tensordot(vec, A, axes=([vec.ndim - 1], [0])).reshape(-1, A.shape[2])
+    return vec.reshape(-1)
+
+
+def test_complex_two_site_algorithms(be):
+    """tsvd-based steps on complex (bond-embedded) states, cplx.split_two_site: TDVP2 in real time is exact at full bond
+    dimension (dense expm), truncated TDVP2 / DMRG2 agree with the oracle's complex128 runs on gauge-invariant
+    quantities; the SU(2)-degenerate Schmidt multiplets of the Heisenberg chain exercise the cluster handling at the cut."""
+    import scipy.linalg as sla
+    mk = _mk()
+    rng = np.random.default_rng(29)
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)
+    L = 6
+    dims = mo.FiniteMPS.random(L, 2, 64, np.random.default_rng(0)).bond_dims()
+    shp = [(1 if i == 0 else dims[i - 1], 2, dims[i]) for i in range(L)]
+    As = [rng.random(s) - 0.5 + 1j * (rng.random(s) - 0.5) for s in shp]
+    pg, po = mk.FiniteMPS(As, normalize=True, be=be), mo.FiniteMPS(As, normalize=True)
+    v0 = mo.mps_to_vector(po)
+    assert np.abs(_dense_state_c(pg) - v0).max() < 1e-12
+    ex = sla.expm(-1j * 0.1 * mo.dense_hamiltonian(Ho, L)) @ v0
+    p2, _ = mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP2(trunc_dim=64))
+    assert np.abs(_dense_state_c(p2) - ex).max() < 1e-10
+    # truncating runs: L = 8, D = 6 kept of up to 16
+    L = 8
+    dims = mo.FiniteMPS.random(L, 2, 6, np.random.default_rng(0)).bond_dims()
+    shp = [(1 if i == 0 else dims[i - 1], 2, dims[i]) for i in range(L)]
+    As = [rng.random(s) - 0.5 + 1j * (rng.random(s) - 0.5) for s in shp]
+    pg, po = mk.FiniteMPS(As, normalize=True, be=be), mo.FiniteMPS(As, normalize=True)
+    p1, e1 = mk.timestep(pg, Hg, 0.0, 0.05, mk.TDVP2(trunc_dim=6))
+    q1, f1 = mo.tdvp2_timestep(po, Ho, 0.0, 0.05, truncdim=6)
+    assert p1.bond_dims() == q1.bond_dims() and max(p1.bond_dims()) <= 6
+    vg, vo = _dense_state_c(p1), mo.mps_to_vector(q1)
+    assert abs(abs(np.vdot(vo, vg)) / (np.linalg.norm(vo) * np.linalg.norm(vg)) - 1) < 1e-8   # same state up to truncation-level freedom
+    Eg = float(np.sum(mk.expectation_value(p1, Hg, e1)))
+    Eo = float(np.sum(mo.expectation_value(q1, Ho, f1)).real)
+    assert abs(Eg - Eo) < 1e-7 * abs(Eo)
+    pd, ed, epsd = mk.find_groundstate(pg, Hg, mk.DMRG2(tol=1e-10, maxiter=8, trunc_dim=16))
+    Ed = float(np.sum(mk.expectation_value(pd, Hg, ed)))
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
+    assert abs(Ed - e0) < 1e-9 * abs(e0)                       # D = 16 is the full bond dimension of L = 8
+    _, _, _, logo = mo.dmrg2(po, Ho, truncdim=16, tol=1e-10, maxiter=8)
+    assert abs(Ed - logo[-1][1]) <= 1e-9 * abs(Ed)

@@ -208,8 +208,6 @@ def test_complex_states_by_bond_embedding(cb):
     p3, e3, eps = mk.find_groundstate(pg, Hg, mk.DMRG(tol=1e-10, maxiter=8))
     _, _, epso, logo = mo.dmrg(po, Ho, tol=1e-10, maxiter=8)
     assert abs(np.sum(mk.expectation_value(p3, Hg, e3)) - logo[-1][1]) < 1e-10 * abs(logo[-1][1])
-    with pytest.raises(NotImplementedError):
-        mk.timestep(pg, Hg, 0.0, 0.1, mk.TDVP2())
 
 
 def test_complex_infinite_mps_vumps(cb):
