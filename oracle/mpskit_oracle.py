@@ -12,8 +12,11 @@ own output; the oracle is pinned instead by
   (2) dense exact diagonalisation / free-fermion energies,
   (3) the energies recorded in the reference's rendered docs
       (docs/src/examples/quantum1d/3.ising-dqpt/index.md:48,118 ; 1.ising-cft/index.md:362),
-  (4) the property tests of test/operators.jl:207-225 and test/states.jl:25-28.
-See tests/test_oracle_*.py.
+  (4) the property tests of test/operators.jl:207-225 and test/states.jl:25-28,
+  (5) time evolution (tdvp.jl, integrators.jl): the projector-splitting integrator is exact at full bond
+      dimension, so TDVP / TDVP2 steps must equal the dense exp(-i dt H) psi0 (real, imaginary, mixed dt),
+  (6) changebonds / IDMRG1 restatements: state invariance under expansion, the recorded iTFI energy.
+See tests/test_oracle.py.
 
 Index conventions (TensorKit order):
   MPS tensor  x[a, s, b]      (V_l (x) P <- V_r)               shape (Dl, d, Dr)
