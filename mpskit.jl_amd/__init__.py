@@ -9,6 +9,6 @@ from .operators import MPOHamiltonian, LazySum, heisenberg_XXX, transverse_field
 from .states import FiniteMPS, InfiniteMPS  # noqa: F401,E402
 from .environments import FinEnv, MPOHamInfEnv, MultipleEnvironments, environments  # noqa: F401,E402
 from .derivatives import ddAC, ddAC2, ddC, MPO_ddAC, MPO_ddAC2, MPO_ddC  # noqa: F401,E402
-from .algorithms import (DMRG, DMRG2, VUMPS, IDMRG1, TDVP, TDVP2, Arnoldi, find_groundstate, calc_galerkin,  # noqa: F401,E402
+from .algorithms import (DMRG, DMRG2, VUMPS, IDMRG1, IDMRG2, TDVP, TDVP2, Arnoldi, find_groundstate, calc_galerkin,  # noqa: F401,E402
                          expectation_value, timestep, time_evolve)
 from .changebonds import changebonds, OptimalExpand, SvdCut  # noqa: F401,E402

@@ -158,6 +158,8 @@ def find_groundstate(psi, H, alg=None, envs=None):
         return _vumps(psi, H, alg, envs)
     if isinstance(alg, IDMRG1):
         return _idmrg1(psi, H, alg, envs)
+    if isinstance(alg, IDMRG2):
+        return _idmrg2(psi, H, alg, envs)
     raise TypeError(f"unknown algorithm {alg!r}")
 
 
@@ -559,6 +561,95 @@ def _idmrg1(ost, H, alg: IDMRG1, oenvs=None):  # idmrg.jl:21-77
             eps = 1.0
         if alg.verbosity >= 3:
             print(f"[ Info: IDMRG {it:3d}:\terr = {eps:.10e}\ttime = {time.time() - t0:.2f} sec", flush=True)
+        if eps < alg.tol:
+            break
+    nst = InfiniteMPS.from_tensors(psi.AR, tol=alg.tol_gauge, be=be)
+    return nst, MPOHamInfEnv(nst, H), eps
+
+
+# ---- IDMRG2 (idmrg.jl:79-204) -----------------------------------------------------------------------------
+
+@dataclass
+class IDMRG2:  # idmrg.jl:89-96 ; trscheme = truncerr(1e-6)
+    tol: float = 1e-12
+    tol_gauge: float = 1e-14
+    maxiter: int = 100
+    krylovdim: int = 30
+    verbosity: int = 0
+    trunc_dim: int = 0
+    trunc_err: float = 1e-6
+    eig_tol_min: float = 1e-12
+    eig_tol_max: float = 1e-5
+    eig_tol_factor: float = 1e-5
+
+
+def _host_inv(be, C: DTensor):
+    """inv(C) of a bond matrix (D x D, tiny next to the contractions): on the host, like the reference's dense inv."""
+    return be.upload(np.linalg.inv(be.download(C)))
+
+
+def _idmrg2(ost, H, alg: IDMRG2, oenvs=None):  # idmrg.jl:97-204
+    from .derivatives import MPO_ddAC2
+    from .states import mul_CA
+    be = ost.be
+    n = len(ost)
+    if n < 2:
+        raise ValueError("unit cell should be >= 2")
+    _no_cplx(ost, "IDMRG2")
+    oenvs = MPOHamInfEnv(ost, H) if oenvs is None else oenvs
+    eps = _calc_galerkin_inf(ost, oenvs)
+    psi = InfiniteMPS(list(ost.AL), list(ost.AR), list(ost.CR), list(ost.AC), be)
+    envs = IDMRGEnv(ost, oenvs)
+    ws = krylov.KrylovWorkspace(be)
+    t0 = time.time()
+
+    def solve(ac2, pl, pr, eig):
+        h = MPO_ddAC2(be, envs.opp[pl], envs.opp[pr], envs.lw[pl], envs.rw[pr])
+        _, new = fixedpoint(be, h, ac2, eig, ws)
+        al, c, ar = _split_two_site(be, new, alg)
+        be.scal(1.0 / be.norm(c), c)                                    # normalize!(c)
+        return al, c, ar
+
+    for it in range(1, alg.maxiter + 1):
+        eig = Arnoldi(tol=updatetol(alg.eig_tol_min, alg.eig_tol_max, alg.eig_tol_factor, it, eps), krylovdim=alg.krylovdim)
+        for pos in range(n - 1):
+            al, c, ar = solve(_two_site_tensor(be, psi.AC[pos], psi.AR[pos + 1]), pos, pos + 1, eig)
+            psi.AL[pos], psi.CR[pos], psi.AR[pos + 1] = al, c, ar
+            psi.AC[pos + 1] = mul_CA(be, c, ar)
+            envs.update_leftenv(psi, pos + 1)
+            envs.update_rightenv(psi, pos)
+        # edge (sites n-1, 0):  AC[end] inv(CR[end]) . AL[1] CR[1]
+        left = mul_AC(be, psi.AC[n - 1], _host_inv(be, psi.CR[n - 1]))
+        right = mul_AC(be, psi.AL[0], psi.CR[0])
+        al, c, ar = solve(_two_site_tensor(be, left, right), n - 1, 0, eig)
+        psi.AC[n - 1] = mul_AC(be, al, c)
+        psi.AL[n - 1], psi.CR[n - 1], psi.AR[0] = al, c, ar
+        psi.AC[0] = mul_CA(be, c, ar)
+        psi.AL[0] = mul_AC(be, psi.AC[0], _host_inv(be, psi.CR[0]))
+        c_cur = c
+        envs.update_leftenv(psi, 0)
+        envs.update_rightenv(psi, n - 1)
+        for pos in range(n - 2, -1, -1):
+            al, c, ar = solve(_two_site_tensor(be, psi.AL[pos], psi.AC[pos + 1]), pos, pos + 1, eig)
+            psi.AL[pos], psi.CR[pos], psi.AR[pos + 1] = al, c, ar
+            psi.AC[pos] = mul_AC(be, al, c)
+            psi.AC[pos + 1] = mul_CA(be, c, ar)
+            envs.update_leftenv(psi, pos + 1)
+            envs.update_rightenv(psi, pos)
+        # edge again:  CR[end-1] AR[end] . inv(CR[end]) AC[1]
+        left = mul_CA(be, psi.CR[n - 2], psi.AR[n - 1])
+        right = mul_CA(be, _host_inv(be, psi.CR[n - 1]), psi.AC[0])
+        al, c, ar = solve(_two_site_tensor(be, left, right), n - 1, 0, eig)
+        psi.AR[n - 1] = mul_CA(be, _host_inv(be, psi.CR[n - 2]), mul_AC(be, al, c))
+        psi.AL[n - 1], psi.CR[n - 1], psi.AR[0] = al, c, ar
+        psi.AC[0] = mul_CA(be, c, ar)
+        envs.update_leftenv(psi, 0)
+        envs.update_rightenv(psi, n - 1)
+        a, b = be.download(c), be.download(c_cur)
+        k = min(a.shape[0], b.shape[0])
+        eps = float(np.linalg.norm(a[:k, :k] - b[:k, :k]))
+        if alg.verbosity >= 3:
+            print(f"[ Info: IDMRG2 {it:3d}:\terr = {eps:.10e}\ttime = {time.time() - t0:.2f} sec", flush=True)
         if eps < alg.tol:
             break
     nst = InfiniteMPS.from_tensors(psi.AR, tol=alg.tol_gauge, be=be)

@@ -1449,3 +1449,76 @@ def idmrg1(psi, H, tol=1e-12, tol_gauge=1e-14, maxiter=100, krylovdim=30, verbos
     nst = InfiniteMPS.from_tensors(AR, tol=tol_gauge)
     nenvs = MPOHamInfEnv(nst, H)
     return nst, nenvs, eps
+
+
+def idmrg2(psi, H, truncdim=None, truncerr=1e-6, tol=1e-12, tol_gauge=1e-14, maxiter=100, krylovdim=30, verbose=False):
+    """find_groundstate(psi::InfiniteMPS, H, IDMRG2(trscheme))  (idmrg.jl:97-204), unit cell >= 2."""
+    n, odim = len(psi), H.odim
+    if n < 2:
+        raise ValueError("unit cell should be >= 2")
+    if truncdim is not None:
+        truncerr = None
+    envs0 = MPOHamInfEnv(psi, H)
+    eps = calc_galerkin_inf(psi, envs0)
+    AL, AR, AC, CR = list(psi.AL), list(psi.AR), list(psi.AC), list(psi.CR)
+    lw = [[envs0.lw[i][s].copy() for i in range(odim)] for s in range(n)]
+    rw = [[envs0.rw[i][s].copy() for i in range(odim)] for s in range(n)]
+
+    def solve(ac2, pl, pr, eig_tol):
+        h1, h2, GL, GR = H[pl], H[pr], lw[pl], rw[pr]
+        _, new, _ = eigsolve_sr(lambda x: dAC2(x, h1, h2, GL, GR), ac2, tol=eig_tol, krylovdim=krylovdim)
+        al, s, ar, _ = tsvd(new, truncdim=truncdim, truncerr=truncerr)
+        s = s / np.linalg.norm(s)
+        return al, np.diag(s).astype(new.dtype), np.transpose(ar, (0, 2, 1))          # ar: [k, s2, b]
+
+    def upd_l(pos):      # lw[pos] = lw[pos-1] * TM(AL[pos-1])
+        p = (pos - 1) % n
+        lw[pos % n] = transfer_left(lw[p], H[p], AL[p], AL[p])
+
+    def upd_r(pos):      # rw[pos] = TM(AR[pos+1]) * rw[pos+1]
+        p = (pos + 1) % n
+        rw[pos % n] = transfer_right(rw[p], H[p], AR[p], AR[p])
+
+    for it in range(1, maxiter + 1):
+        eig_tol = updatetol(1e-12, 1e-5, 1e-5, it, eps)
+        for pos in range(n - 1):
+            ac2 = np.einsum("asm,mrb->asbr", AC[pos], AR[pos + 1])
+            al, c, ar = solve(ac2, pos, pos + 1, eig_tol)
+            AL[pos], CR[pos], AR[pos + 1] = al, c, ar
+            AC[pos + 1] = np.einsum("km,msb->ksb", c, ar)
+            upd_l(pos + 1)
+            upd_r(pos)
+        # edge: sites (n-1, 0)
+        ac2 = np.einsum("asm,mk,krl,lb->asbr", AC[n - 1], np.linalg.inv(CR[n - 1]), AL[0], CR[0])
+        al, c, ar = solve(ac2, n - 1, 0, eig_tol)
+        AC[n - 1] = np.einsum("asm,mk->ask", al, c)
+        AL[n - 1], CR[n - 1], AR[0] = al, c, ar
+        AC[0] = np.einsum("km,msb->ksb", c, ar)
+        AL[0] = np.einsum("asm,mk->ask", AC[0], np.linalg.inv(CR[0]))
+        C_current = c
+        upd_l(0)
+        upd_r(n - 1)
+        for pos in range(n - 2, -1, -1):
+            ac2 = np.einsum("asm,mrb->asbr", AL[pos], AC[pos + 1])
+            al, c, ar = solve(ac2, pos, pos + 1, eig_tol)
+            AL[pos], CR[pos], AR[pos + 1] = al, c, ar
+            AC[pos] = np.einsum("asm,mk->ask", al, c)
+            AC[pos + 1] = np.einsum("km,msb->ksb", c, ar)
+            upd_l(pos + 1)
+            upd_r(pos)
+        ac2 = np.einsum("am,msk,kl,lrb->asbr", CR[n - 2], AR[n - 1], np.linalg.inv(CR[n - 1]), AC[0])
+        al, c, ar = solve(ac2, n - 1, 0, eig_tol)
+        alc = np.einsum("asm,mk->ask", al, c)
+        AR[n - 1] = np.einsum("am,msb->asb", np.linalg.inv(CR[n - 2]), alc)
+        AL[n - 1], CR[n - 1], AR[0] = al, c, ar
+        AC[0] = np.einsum("km,msb->ksb", c, ar)
+        upd_l(0)
+        upd_r(n - 1)
+        k = min(C_current.shape[0], c.shape[0])
+        eps = float(np.linalg.norm(c[:k, :k] - C_current[:k, :k]))
+        if verbose:
+            print(f"IDMRG2 {it:3d}: err = {eps:.10e}  D = {[a.shape[2] for a in AL]}")
+        if eps < tol:
+            break
+    nst = InfiniteMPS.from_tensors(AR, tol=tol_gauge)
+    return nst, MPOHamInfEnv(nst, H), eps

@@ -446,3 +446,20 @@ def test_complex_two_site_algorithms(be):
     assert abs(Ed - e0) < 1e-9 * abs(e0)                       # D = 16 is the full bond dimension of L = 8
     _, _, _, logo = mo.dmrg2(po, Ho, truncdim=16, tol=1e-10, maxiter=8)
     assert abs(Ed - logo[-1][1]) <= 1e-9 * abs(Ed)
+
+
+def test_idmrg2_grows_bond_and_matches_oracle(be):
+    """idmrg.jl:97-204 on the HIP path: two-site unit cell of the infinite TFI chain, D grown 6 -> 10 by the
+    truncated two-site updates, energy per site = the value recorded in the reference docs and the oracle's IDMRG2."""
+    mk = _mk()
+    H, Ho = mk.transverse_field_ising(1.0, 0.5, be=be), mo.tfi_mpo(1.0, 0.5)
+    rng = np.random.default_rng(11)
+    A, B = rng.random((6, 2, 6)), rng.random((6, 2, 6))
+    p, e, eps = mk.find_groundstate(mk.InfiniteMPS.from_tensors([A, B], be=be), H,
+                                    mk.IDMRG2(tol=1e-10, maxiter=200, trunc_dim=10))
+    E = mk.expectation_value(p, H, e)
+    assert eps < 1e-10 and p.AL[0].shape == (10, 2, 10)
+    assert abs(float(np.sum(E)) / 2 - (-1.063544409973)) < 5e-11
+    po, eo, epso = mo.idmrg2(mo.InfiniteMPS.from_tensors([A, B]), Ho, truncdim=10, tol=1e-10, maxiter=200)
+    Eo = float(np.sum(mo.expectation_value_inf(po, Ho, eo)).real)
+    assert abs(float(np.sum(E)) - Eo) <= 1e-9 * abs(Eo)

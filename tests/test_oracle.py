@@ -213,3 +213,13 @@ def test_idmrg1_restatement_recorded_energy():
     p, e, eps = mo.idmrg1(mo.InfiniteMPS.from_tensors([A]), H, tol=1e-10, maxiter=300)
     assert eps < 1e-10
     assert abs(np.sum(mo.expectation_value_inf(p, H, e)).real - (-1.063544409973)) < 5e-12
+
+
+def test_idmrg2_restatement_recorded_energy():
+    """idmrg.jl:97-204 restated: two-site unit cell iTFI, bond grown to 10 -> recorded energy per site."""
+    H = mo.tfi_mpo(1.0, 0.5)
+    rng = np.random.default_rng(11)
+    p, e, eps = mo.idmrg2(mo.InfiniteMPS.from_tensors([rng.random((6, 2, 6)), rng.random((6, 2, 6))]), H,
+                          truncdim=10, tol=1e-10, maxiter=200)
+    assert eps < 1e-10 and p.AL[0].shape == (10, 2, 10)
+    assert abs(np.sum(mo.expectation_value_inf(p, H, e)).real / 2 - (-1.063544409973)) < 5e-11
