@@ -175,6 +175,9 @@ int mpsk_vgs_step(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* 
  *                    xs[0..k), then y <- y / ||y||; host_h[j] = coefficient on xs[j], *host_beta = ||y|| */
 int mpsk_vorth_step(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* y, double* host_h,
                     double* host_beta);
+/* the same step without a host synchronisation: the 2k+1 scalars (h1[k], h2[k], |remainder|^2; h = h1 + h2,
+ * beta = sqrt of the last) stay in dev_out (device memory, >= 2k+1 doubles) */
+int mpsk_vorth_step_dev(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* y, void* dev_out);
 /* y = sum_j coefs[j] xs[j]   (Ritz vector assembly) */
 int mpsk_vlincomb(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y);
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mpsk_vmultidot": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p],
     "mpsk_vgs_step": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p],
     "mpsk_vorth_step": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p, c_double_p],
+    "mpsk_vorth_step_dev": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, C.c_void_p],
     "mpsk_vlincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, c_double_p, C.c_void_p],
 }
 # symbols without the (ctx, ...) -> int shape

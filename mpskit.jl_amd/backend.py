@@ -328,6 +328,11 @@ class Backend:
               "mpsk_vorth_step")
         return np.array(out[:]), beta.value
 
+    def orth_step_dev(self, xs, y: DTensor, slot: DTensor, offset: int):
+        """orth_step without the host sync: the 2k+1 scalars go to slot[offset : offset + 2k + 1] on the device."""
+        check(self.lib.mpsk_vorth_step_dev(self.ctx, y.size, len(xs), self._ptrs(xs), y.ptr, slot.ptr + 8 * offset),
+              "mpsk_vorth_step_dev")
+
     def lincomb(self, xs, coefs, out: DTensor = None):
         y = self.empty(xs[0].shape) if out is None else out
         cf = (C.c_double * len(xs))(*[float(c) for c in coefs])

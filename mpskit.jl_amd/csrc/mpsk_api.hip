@@ -780,6 +780,26 @@ int mpsk_vorth_step(mpsk_ctx* c, int64_t n, int k, const void* const* xs, void* 
   return MPSK_OK;
 }
 
+// Same fused step with the 2k+1 scalars left on the DEVICE (dev_out: first-pass dots [k], second-pass dots [k],
+// squared norm of the remainder): no host synchronisation, so a fixed-length Krylov recurrence can be enqueued
+// back to back and its small projected matrix is read once at the end.
+int mpsk_vorth_step_dev(mpsk_ctx* c, int64_t n, int k, const void* const* xs, void* y, void* dev_out) {
+  REQUIRE(c && xs && y && dev_out, "NULL argument");
+  REQUIRE(k > 0 && 2 * k + 1 <= MAXK && n > 0, "bad k or n");
+  HIPCHK(hipSetDevice(c->device));
+  const double* const* X = (const double* const*)xs;
+  double* yy = (double*)y;
+  double* out = (double*)dev_out;
+  HIPCHK(vec_multidot(X, k, yy, n, out, c->d_partial, c->stream));
+  HIPCHK(vec_multiaxpy(X, out, k, -1.0, yy, n, c->stream));
+  HIPCHK(vec_multidot(X, k, yy, n, out + k, c->d_partial, c->stream));
+  HIPCHK(vec_multiaxpy(X, out + k, k, -1.0, yy, n, c->stream));
+  const double* ys[1] = {yy};
+  HIPCHK(vec_multidot(ys, 1, yy, n, out + 2 * k, c->d_partial, c->stream));
+  HIPCHK(vec_scal_rsqrt_dev(out + 2 * k, yy, n, c->stream));
+  return MPSK_OK;
+}
+
 int mpsk_vlincomb(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y) {
   REQUIRE(c && xs && y && host_coefs, "NULL argument");
   REQUIRE(k > 0 && k <= MAXK && n > 0, "bad k or n");

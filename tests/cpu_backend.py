@@ -237,6 +237,18 @@ class CpuBackend:
             self.scal(1.0 / beta, y)
         return h, beta
 
+    def orth_step_dev(self, xs, y, slot, offset):
+        k = len(xs)
+        h1 = self.gs_step(xs, y)
+        h2 = self.gs_step(xs, y)
+        n2 = self.norm(y) ** 2
+        if n2 > 0:
+            self.scal(1.0 / np.sqrt(n2), y)
+        buf = slot.buf.numpy()
+        buf[offset:offset + k] = h1
+        buf[offset + k:offset + 2 * k] = h2
+        buf[offset + 2 * k] = n2
+
     def lincomb(self, xs, coefs, out=None):
         y = self.empty(xs[0].shape) if out is None else out
         v = sum(float(c) * self._v(x) for c, x in zip(coefs, xs))
