@@ -12,3 +12,4 @@ from .derivatives import ddAC, ddAC2, ddC, MPO_ddAC, MPO_ddAC2, MPO_ddC  # noqa:
 from .algorithms import (DMRG, DMRG2, VUMPS, IDMRG1, IDMRG2, TDVP, TDVP2, Arnoldi, find_groundstate, calc_galerkin,  # noqa: F401,E402
                          expectation_value, timestep, time_evolve)
 from .changebonds import changebonds, OptimalExpand, SvdCut  # noqa: F401,E402
+from .excitations import excitations, FiniteExcited, ProjectionOperator  # noqa: F401,E402

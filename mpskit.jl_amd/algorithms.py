@@ -109,6 +109,9 @@ def expectation_value(psi, H, envs):
     be = psi.be
     if isinstance(envs, MultipleEnvironments):          # expval of a LazySum: sum of the terms' (lazysum.jl)
         return sum(f * expectation_value(psi, h, e) for f, h, e in zip(H.fs, H, envs.envs))
+    if hasattr(envs, "vector"):                         # ProjectionOperator term (excitations.py)
+        from .excitations import _expval_projection
+        return _expval_projection(psi, H, envs)
     if isinstance(psi, FiniteMPS):
         L = len(psi)
         ens = np.zeros(L)

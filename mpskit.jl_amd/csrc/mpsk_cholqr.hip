@@ -476,7 +476,15 @@ __global__ __launch_bounds__(256) void cq_sumsq_kernel(const double* __restrict_
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) out[1 + blockIdx.x] = red[0] + red[1] + red[2] + red[3];   // per-block partial
+}
+// out[0] = sum of the per-block partials in block order (deterministic: no floating-point atomics)
+__global__ __launch_bounds__(64) void cq_sumsq_final_kernel(double* __restrict__ out, int nblocks) {
+  if (threadIdx.x == 0) {
+    double acc = 0.0;
+    for (int i = 0; i < nblocks; ++i) acc += out[1 + i];
+    out[0] = acc;
+  }
 }
 __global__ __launch_bounds__(256) void cq_perturb_kernel(const double* __restrict__ A, int lda, int m, int n,
                                                          double* __restrict__ X, int ldx, const double* __restrict__ sumsq) {
@@ -496,9 +504,9 @@ hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int 
   const int npad = b.npad;
   hipError_t e;
   double* sumsq = b.T;                       // T is free until the first pass
-  if ((e = hipMemsetAsync(sumsq, 0, sizeof(double), s)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
   hipLaunchKernelGGL(cq_sumsq_kernel, dim3(512), dim3(256), 0, s, A, lda, m, n, sumsq);
+  hipLaunchKernelGGL(cq_sumsq_final_kernel, dim3(1), dim3(64), 0, s, sumsq, 512);
   hipLaunchKernelGGL(cq_perturb_kernel, dim3(1024), dim3(256), 0, s, A, lda, m, n, b.Qa, m, sumsq);
   double *acc = b.R1, *cur = b.R2, *tmp = b.R3;
   double *X = b.Qa, *Y = b.Qb;

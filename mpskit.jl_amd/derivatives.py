@@ -68,6 +68,9 @@ def ddC(pos, psi, H, envs):  # ∂∂C  derivatives.jl:34-36
 def ddAC(pos, psi, H, envs):  # ∂∂AC  derivatives.jl:44-46
     if _is_lazy(H, envs):
         return _lazy(ddAC, pos, psi, H, envs)
+    if hasattr(envs, "vector"):          # ProjectionOperator term (excitations.py): rank-one |v><v|
+        from .excitations import Proj_ddAC
+        return Proj_ddAC(psi.be, envs.vector(pos, psi))
     opp = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
     return MPO_ddAC(psi.be, opp, envs.leftenv(pos, psi), envs.rightenv(pos, psi))
 

@@ -1,0 +1,116 @@
+"""excitations(H, FiniteExcited(), psi)  (src/algorithms/excitation/dmrgexcitation.jl:13-36): excited states of a finite
+chain as ground states of  H + weight * sum_i |psi_i><psi_i|.  The projection operators are LazySum terms whose
+environments are plain overlap transfers <psi_i| . |psi> (mpsk_transfer_left/right without an MPO) and whose effective
+"Hamiltonian" at a site is the rank-one operator |v><v| with v = <psi_i| contracted into the current mixed-gauge
+basis (two GEMMs) -- operators/projection.jl in the reference."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .backend import DTensor
+from .algorithms import DMRG, find_groundstate, expectation_value
+from .environments import FinEnv, MultipleEnvironments
+from .operators import LazySum
+from .states import FiniteMPS
+
+
+@dataclass
+class FiniteExcited:  # dmrgexcitation.jl:10-13
+    gsalg: object = field(default_factory=DMRG)
+    weight: float = 10.0
+
+
+class ProjectionOperator:
+    """|psi><psi| for a fixed FiniteMPS (operators/projection.jl)."""
+
+    def __init__(self, psi: FiniteMPS):
+        self.psi = psi
+
+
+class OverlapEnv:
+    """environments(psi, ProjectionOperator(target)): left / right overlap environments [1][bra = target, ket = psi]
+    with the identity-based invalidation of FinEnv."""
+
+    def __init__(self, psi, op: ProjectionOperator):
+        be = self.be = psi.be
+        L = len(psi)
+        self.H, self.t = op, op.psi
+        self.lefts = [be.upload(np.ones((1, 1, 1)))] + [None] * L
+        self.rights = [None] * L + [be.upload(np.ones((1, 1, 1)))]
+        self.ldeps, self.rdeps = [None] * L, [None] * L
+
+    def leftenv(self, ind, psi):
+        a = next((i for i in range(ind) if psi.AL(i) is not self.ldeps[i]), None)
+        if a is not None:
+            for j in range(a, ind):
+                al = psi.AL(j)
+                self.lefts[j + 1] = self.be.transfer_left(None, self.lefts[j], al, self.t.AL(j))
+                self.ldeps[j] = al
+        return self.lefts[ind]
+
+    def rightenv(self, ind, psi):
+        L = len(psi)
+        a = next((i for i in range(L - 1, ind, -1) if psi.AR(i) is not self.rdeps[i]), None)
+        if a is not None:
+            for j in range(a, ind, -1):
+                ar = psi.AR(j)
+                self.rights[j] = self.be.transfer_right(None, self.rights[j + 1], ar, self.t.AR(j))
+                self.rdeps[j] = ar
+        return self.rights[ind + 1]
+
+    def vector(self, pos, psi):
+        """|target> in the current mixed-gauge basis at site pos:  v[a, s, b] = GL[a', a] ACt[a', s, b'] GR[b, b']."""
+        be = self.be
+        GL, GR = self.leftenv(pos, psi), self.rightenv(pos, psi)        # (1, Dt, D), (1, D', Dt')
+        act = self.t.AC(pos)
+        Dt, d, Dtr = act.shape
+        D, Dp = GL.shape[2], GR.shape[1]
+        t1 = be.gemm(DTensor(GL.buf, (Dt, D)), act.reshape(Dt, d * Dtr), transA=True)          # (D, d Dt')
+        v = be.gemm(t1.reshape(D * d, Dtr), DTensor(GR.buf, (Dp, Dtr)), transB=True)           # (D d, D')
+        return v.reshape(D, d, Dp)
+
+
+class Proj_ddAC:
+    """effective operator of |target><target| at a site: y = v <v, x>."""
+
+    def __init__(self, be, v: DTensor):
+        self.be, self.v = be, v
+
+    def __call__(self, x: DTensor, out: DTensor = None):
+        y = self.be.empty(*x.shape) if out is None else out
+        self.be.axpby(self.be.dot(self.v, x), self.v, 0.0, y)
+        return y
+
+    __mul__ = __call__
+
+
+def _expval_projection(psi, op, envs):
+    """<psi| target><target |psi> / <psi|psi>, reported on site 0 (the other sites carry 0)."""
+    pos = 0
+    v = envs.vector(pos, psi)
+    ac = psi.AC(pos)
+    be = psi.be
+    out = np.zeros(len(psi))
+    out[0] = be.dot(v, ac) ** 2 / be.norm(ac) ** 2
+    return out
+
+
+def excitations(H, alg: FiniteExcited, psi0: FiniteMPS, num=1, init=None):
+    """excitations(H, FiniteExcited(gsalg, weight), psi0; num) -> (energies, states)."""
+    if getattr(psi0, "cplx", False):
+        raise NotImplementedError("FiniteExcited on complex (embedded) states: the projector needs both |v> and i|v>")
+    be = psi0.be
+    L = len(psi0)
+    states, ens, out = [psi0], [], []
+    for _ in range(num):
+        start = FiniteMPS([be.copy(psi0.AC(i)) for i in range(L)], normalize=True, be=be) if init is None else init.copy()
+        ops = [H] + [ProjectionOperator(s) for s in states]
+        Hs = LazySum(ops, [1.0] + [alg.weight] * len(states))
+        envs = MultipleEnvironments(Hs, [FinEnv(start, H)] + [OverlapEnv(start, o) for o in ops[1:]])
+        ne, _, _ = find_groundstate(start, Hs, alg.gsalg, envs)
+        states.append(ne)
+        out.append(ne)
+        ens.append(float(np.sum(expectation_value(ne, H, FinEnv(ne, H)))))
+    return ens, out

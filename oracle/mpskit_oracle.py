@@ -1522,3 +1522,76 @@ def idmrg2(psi, H, truncdim=None, truncerr=1e-6, tol=1e-12, tol_gauge=1e-14, max
             break
     nst = InfiniteMPS.from_tensors(AR, tol=tol_gauge)
     return nst, MPOHamInfEnv(nst, H), eps
+
+
+# --------------------------------------------------------------------------------------
+# FiniteExcited (src/algorithms/excitation/dmrgexcitation.jl:13-36, operators/projection.jl)
+# --------------------------------------------------------------------------------------
+
+class OverlapEnv:
+    """environments(psi, ProjectionOperator(target)): overlap transfer of <target| with |psi>, same lazy identity
+    based invalidation as FinEnv (projection operators reuse the FinEnv machinery in the reference)."""
+
+    def __init__(self, psi, target):
+        L = len(psi)
+        self.t = target
+        self.lefts = [np.ones((1, 1, 1))] + [None] * L
+        self.rights = [None] * L + [np.ones((1, 1, 1))]
+        self.ldeps, self.rdeps = [None] * L, [None] * L
+
+    def leftenv(self, ind, psi):
+        a = next((i for i in range(ind) if psi.AL(i) is not self.ldeps[i]), None)
+        if a is not None:
+            for j in range(a, ind):
+                self.lefts[j + 1] = transfer_left_block(self.lefts[j], None, psi.AL(j), self.t.AL(j))
+                self.ldeps[j] = psi.AL(j)
+        return self.lefts[ind]
+
+    def rightenv(self, ind, psi):
+        L = len(psi)
+        a = next((i for i in range(L - 1, ind, -1) if psi.AR(i) is not self.rdeps[i]), None)
+        if a is not None:
+            for j in range(a, ind, -1):
+                self.rights[j] = transfer_right_block(self.rights[j + 1], None, psi.AR(j), self.t.AR(j))
+                self.rdeps[j] = psi.AR(j)
+        return self.rights[ind + 1]
+
+    def vector(self, pos, psi):
+        """|target> expressed in the current mixed-gauge basis at site pos: v[a, s, b]."""
+        GL, GR = self.leftenv(pos, psi)[:, 0, :], self.rightenv(pos, psi)[:, 0, :]     # [bra, ket], [ket, bra]
+        return np.einsum("pa,psq,bq->asb", GL, self.t.AC(pos), GR)
+
+
+def excitations_finite(H, psi0, num=1, weight=10.0, tol=1e-10, maxiter=30, krylovdim=30):
+    """excitations(H, FiniteExcited(gsalg = DMRG(), weight), psi0; num): 1-site DMRG on H + weight sum_i |psi_i><psi_i|,
+    initial state built from the AC tensors of the first state (dmrgexcitation.jl:16-19).  Returns (energies, states)."""
+    states, ens = [psi0], []
+    L = len(psi0)
+    for _ in range(num):
+        psi = FiniteMPS([psi0.AC(i).copy() for i in range(L)], normalize=True)
+        envs = FinEnv(psi, H)
+        ovs = [OverlapEnv(psi, t) for t in states]
+        for it in range(maxiter):
+            eps = 0.0
+            for pos in list(range(L - 1)) + list(range(L - 1, 0, -1)):
+                GL, GR, slc = envs.leftenv(pos, psi), envs.rightenv(pos, psi), envs.opp[pos]
+                vs = [o.vector(pos, psi) for o in ovs]
+
+                def heff(x):
+                    y = dAC(x, slc, GL, GR)
+                    for v in vs:
+                        y = y + weight * v * np.vdot(v, x)
+                    return y
+                _, vec, _ = eigsolve_sr(heff, psi.AC(pos), tol=1e-12, krylovdim=krylovdim)
+                g = heff(psi.AC(pos))
+                g = g / np.linalg.norm(g)
+                al = psi.AL(pos)
+                M = al.reshape(-1, al.shape[2])
+                gv = g.reshape(M.shape[0], -1)
+                eps = max(eps, float(np.linalg.norm(gv - M @ (M.conj().T @ gv))))
+                psi.set_AC(pos, vec)
+            if eps <= tol:
+                break
+        states.append(psi)
+        ens.append(float(np.sum(expectation_value(psi, H, FinEnv(psi, H))).real))
+    return ens, states[1:]

@@ -463,3 +463,19 @@ def test_idmrg2_grows_bond_and_matches_oracle(be):
     po, eo, epso = mo.idmrg2(mo.InfiniteMPS.from_tensors([A, B]), Ho, truncdim=10, tol=1e-10, maxiter=200)
     Eo = float(np.sum(mo.expectation_value_inf(po, Ho, eo)).real)
     assert abs(float(np.sum(E)) - Eo) <= 1e-9 * abs(Eo)
+
+
+def test_finite_excited_states(be):
+    """excitations(H, FiniteExcited(), psi) (dmrgexcitation.jl:13-36) through the HIP path: first two excited energies
+    of an L = 10 TFI chain vs dense ED; the states are orthogonal to the ground state."""
+    mk = _mk()
+    L = 10
+    Hg, Ho = mk.transverse_field_ising(1.0, 1.3, be=be), mo.tfi_mpo(1.0, 1.3)
+    ev = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))
+    psi = mk.FiniteMPS.random(L, 2, 32, np.random.default_rng(0), be=be)
+    p0, e0, eps0 = mk.find_groundstate(psi, Hg, mk.DMRG(tol=1e-11, maxiter=30))
+    assert abs(float(np.sum(mk.expectation_value(p0, Hg, e0))) - ev[0]) < 1e-10 * abs(ev[0])
+    ens, sts = mk.excitations(Hg, mk.FiniteExcited(gsalg=mk.DMRG(tol=1e-10, maxiter=30), weight=10.0), p0, num=2)
+    assert abs(ens[0] - ev[1]) < 1e-8 and abs(ens[1] - ev[2]) < 1e-8
+    v0, v1, v2 = _dense_state(be, p0), _dense_state(be, sts[0]), _dense_state(be, sts[1])
+    assert abs(v0 @ v1) < 1e-7 and abs(v0 @ v2) < 1e-7 and abs(v1 @ v2) < 1e-7

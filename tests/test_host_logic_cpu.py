@@ -223,3 +223,19 @@ def test_complex_infinite_mps_vumps(cb):
     p, e, eps = mk.find_groundstate(psi, H, mk.VUMPS(tol=1e-10, maxiter=60))
     _, _, _, logo = mo.vumps(po, Ho, tol=1e-10, maxiter=60)
     assert eps < 1e-9 and abs(float(np.sum(mk.expectation_value(p, H, e))) - logo[-1][1]) < 1e-10
+
+
+def test_finite_excited_states_match_ed(cb):
+    """dmrgexcitation.jl:13-36 on the product's host code: the first two excited energies of an L = 8 TFI chain
+    (H + w sum |psi_i><psi_i|, overlap environments, rank-one projector derivative) equal dense ED and the oracle."""
+    L = 8
+    Hg, Ho = mk.transverse_field_ising(1.0, 1.3, be=cb), mo.tfi_mpo(1.0, 1.3)
+    ev = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))
+    psi = mk.FiniteMPS.random(L, 2, 16, np.random.default_rng(0), be=cb)
+    p0, e0, eps0 = mk.find_groundstate(psi, Hg, mk.DMRG(tol=1e-11, maxiter=30))
+    assert abs(float(np.sum(mk.expectation_value(p0, Hg, e0))) - ev[0]) < 1e-10
+    ens, sts = mk.excitations(Hg, mk.FiniteExcited(gsalg=mk.DMRG(tol=1e-10, maxiter=30)), p0, num=2)
+    assert abs(ens[0] - ev[1]) < 1e-8 and abs(ens[1] - ev[2]) < 1e-8
+    ens_o, _ = mo.excitations_finite(Ho, mo.FiniteMPS.random(L, 2, 16, np.random.default_rng(0)) if False else
+                                     mo.dmrg(mo.FiniteMPS.random(L, 2, 16, np.random.default_rng(0)), Ho, tol=1e-11, maxiter=30)[0], num=2)
+    assert abs(ens[0] - ens_o[0]) < 1e-8 and abs(ens[1] - ens_o[1]) < 1e-8

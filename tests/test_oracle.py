@@ -223,3 +223,13 @@ def test_idmrg2_restatement_recorded_energy():
                           truncdim=10, tol=1e-10, maxiter=200)
     assert eps < 1e-10 and p.AL[0].shape == (10, 2, 10)
     assert abs(np.sum(mo.expectation_value_inf(p, H, e)).real / 2 - (-1.063544409973)) < 5e-11
+
+
+def test_finite_excited_restatement_matches_ed():
+    """dmrgexcitation.jl:13-36 restated: penalty-DMRG excited energies == dense ED (L = 8 TFI, full bond dimension)."""
+    L = 8
+    H = mo.tfi_mpo(1.0, 1.3)
+    ev = np.linalg.eigvalsh(mo.dense_hamiltonian(H, L))
+    p0, _, _, log = mo.dmrg(mo.FiniteMPS.random(L, 2, 16, np.random.default_rng(0)), H, tol=1e-11, maxiter=30)
+    ens, _ = mo.excitations_finite(H, p0, num=2)
+    assert abs(log[-1][1] - ev[0]) < 1e-10 and abs(ens[0] - ev[1]) < 1e-8 and abs(ens[1] - ev[2]) < 1e-8
