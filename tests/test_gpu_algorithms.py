@@ -479,3 +479,16 @@ def test_finite_excited_states(be):
     assert abs(ens[0] - ev[1]) < 1e-8 and abs(ens[1] - ev[2]) < 1e-8
     v0, v1, v2 = _dense_state(be, p0), _dense_state(be, sts[0]), _dense_state(be, sts[1])
     assert abs(v0 @ v1) < 1e-7 and abs(v0 @ v2) < 1e-7 and abs(v1 @ v2) < 1e-7
+
+
+def test_vumps_spin1_heisenberg_recorded_energy_density(be):
+    """docs/src/examples/quantum1d/2.haldane/index.md:430 : S = 1 Heisenberg energy density -1.401484038967 (the
+    reference's large-D SU(2) result).  VUMPS at D = 64 without symmetries is variational and lands within 1e-6 of it
+    (GEMM-sized bonds: CholeskyQR3 gauge steps, GMRES environments, D^3-scaling matvecs)."""
+    mk = _mk()
+    H = mk.heisenberg_XXX(1.0, be=be)
+    psi = mk.InfiniteMPS.random(3, 64, np.random.default_rng(7), be=be)
+    p, e, eps = mk.find_groundstate(psi, H, mk.VUMPS(tol=1e-9, maxiter=200))
+    E = float(np.sum(mk.expectation_value(p, H, e)))
+    assert eps < 1e-8
+    assert -1.401484038967 - 1e-9 <= E < -1.401484038967 + 1e-6
