@@ -462,8 +462,8 @@ hipError_t cholqr3_finalize(int m, int n, double* Q, int ldq, double* R, int ldr
 // ---- robust variant for ill-conditioned / rank-deficient input (what used to go to Householder) ------------
 // X = A + delta N with N = +-1 pseudo-random and delta = u ||A||_F / sqrt(m): a backward error at rounding level
 // that gives exactly dependent columns a direction of their own (sigma_min ~ u ||A||), so cond(X) <~ 1e16.
-// Each SHIFTED pass divides the condition number by ~1e4..1e5 (sigma -> sigma / sqrt(sigma^2 + s)), so three
-// shifted passes + one plain pass + the first-order pass reach orthogonality 1e-15:  R = R5 R4 R3 R2 R1.
+// Each SHIFTED pass divides the condition number by ~1e4..1e5 (sigma -> sigma / sqrt(sigma^2 + s)), so three (four
+// for n = 4096) shifted passes + one plain pass + the first-order pass reach orthogonality 1e-15:  R = R5 R4 R3 R2 R1.
 __global__ __launch_bounds__(256) void cq_sumsq_kernel(const double* __restrict__ A, int lda, int m, int n,
                                                        double* __restrict__ out) {
   __shared__ double red[4];
@@ -516,9 +516,15 @@ hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int 
     double* t = acc; acc = tmp; tmp = t;
     return ee;
   };
-  for (int p = 0; p < 4; ++p) {
+  // each shifted pass multiplies sigma_min by ~1/sqrt(shift_rel); from cond 1e16 down to <~1e4 needs
+  // ceil(12 / -log10(sqrt(shift_rel))) of them: 3 at 2048 x 1024, 4 at 8192 x 4096
+  const double shift_rel = 11.0 * ((double)m * n + (double)n * (n + 1)) * 1.1102230246251565e-16;
+  int nshift = (int)std::ceil(12.0 / (-0.5 * std::log10(shift_rel)));
+  if (nshift < 3) nshift = 3;
+  if (nshift > 6) nshift = 6;
+  for (int p = 0; p < nshift + 1; ++p) {
     double* Rp = (p == 0) ? acc : cur;
-    if ((e = cq_pass(m, n, npad, X, m, Y, m, Rp, b.Rinv, b.T, /*shifted=*/p < 3, false, d_flag, s)) != hipSuccess) return e;
+    if ((e = cq_pass(m, n, npad, X, m, Y, m, Rp, b.Rinv, b.T, /*shifted=*/p < nshift, false, d_flag, s)) != hipSuccess) return e;
     if (p > 0 && (e = accumulate()) != hipSuccess) return e;
     double* t = X; X = Y; Y = t;
   }
