@@ -78,17 +78,35 @@ class DevicePlumbing:
     def local_dAC(self, H, GLloc, GR, x):
         return self.be.dAC(H, GLloc, GR, x)
 
-    def all_gather_rows(self, yloc, group, world):
+    def _all_gather_flat(self, yloc, group, world):
+        """the collective itself: rank blocks back to back in one device buffer (RCCL on the current stream)."""
         import torch
         import torch.distributed as dist
-        from .backend import DTensor
-        n, d, Dr = yloc.shape
         gathered = torch.empty(world * yloc.size, dtype=torch.float64, device=self.be.device)
         dist.all_gather_into_tensor(gathered, yloc.buf[: yloc.size], group=group)
+        return gathered
+
+    def all_gather_rows(self, yloc, group, world):
+        n, d, Dr = yloc.shape
+        gathered = self._all_gather_flat(yloc, group, world)
         y = self.be.empty(n * world, d, Dr)
         for p in range(world):   # rank p's block -> rows [p*n, (p+1)*n) of every (s, b) column
             self.be.copy2d(n, d * Dr, gathered.data_ptr() + 8 * p * yloc.size, n, y.ptr + 8 * p * n, n * world)
         return y
+
+
+class HostStagedPlumbing(DevicePlumbing):
+    """DevicePlumbing whose collective is staged through the host over gloo: lets TWO ranks share ONE GPU (RCCL
+    refuses duplicate devices), so the device-side row-block extraction and re-interleave are exercised at
+    world_size 2 on a single-GPU box (tests/test_gpu_dist.py).  Test plumbing only."""
+
+    def _all_gather_flat(self, yloc, group, world):
+        import torch
+        import torch.distributed as dist
+        h = yloc.buf[: yloc.size].cpu()
+        outs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(outs, h, group=group)
+        return torch.cat(outs).to(self.be.device)
 
 
 class ShardedMatvec:
@@ -112,10 +130,10 @@ class ShardedMatvec:
         return y
 
 
-def shard_wrapper(be, world, rank, group=None, min_block=64, force=False):
+def shard_wrapper(be, world, rank, group=None, min_block=64, force=False, plumbing=None):
     """Returns wrap(h: MPO_ddAC) -> callable used by dmrg_sweep: sites whose bond dimension is
     shardable run the sharded matvec, the others (chain edges) run replicated."""
-    pl = DevicePlumbing(be)
+    pl = DevicePlumbing(be) if plumbing is None else plumbing
 
     def wrap(h):
         D = h.leftenv.shape[1]
