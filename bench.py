@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--D", type=int, default=1024)
     ap.add_argument("--matvecs", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-env", action="store_true",
+                    help="also shard the environment updates over the ranks (dist.ShardedTransfer: all-reduce / all-gather "
+                         "per update); opt-in until validated on a multi-GPU node")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded-matvec plumbing even with one rank (exercises the RCCL path on a 1-GPU box)")
     args = ap.parse_args()
@@ -123,7 +126,11 @@ def main():
     W = H[0].Wl
     rng = np.random.default_rng(20240213)          # same seed on every rank -> identical replicas
     psi = mk.FiniteMPS.random(L, d, D, rng, normalize=True, be=be)
-    envs = mk.FinEnv(psi, H)
+    tops = None
+    if args.shard_env and (world > 1 or args.force_shard):
+        from mpskit_jl_amd.dist import ShardedTransfer, DevicePlumbing
+        tops = ShardedTransfer(DevicePlumbing(be), world, rank, force=args.force_shard)
+    envs = mk.FinEnv(psi, H, transfer_ops=tops)
     eig = mk.Arnoldi(fixed_matvecs=args.matvecs, krylovdim=max(args.matvecs, 2))
     ws = krylov.KrylovWorkspace(be)
     wrap = shard_wrapper(be, world, rank, force=args.force_shard) if (world > 1 or args.force_shard) else None
@@ -198,7 +205,8 @@ def main():
             "config": {"workload": f"Heisenberg S=1/2 FiniteMPS L={L} D={D} d=2 W={W} fp64, 1-site DMRG sweep "
                                    f"(2L-2 site updates), fixed Krylov budget {args.matvecs} matvecs/site",
                        "parallelism": "single GPU" if world == 1 else f"bond-index sharded matvec x{world} "
-                                                                        "(one RCCL all-gather per matvec)"},
+                                                                        "(one RCCL all-gather per matvec)"
+                                                                        + (", sharded environment updates" if tops else "")},
             "dAC_tflops": None if dac_tflops is None else round(dac_tflops, 3),
             "dAC_frac_of_fp64_mfma_peak": None if dac_tflops is None else round(dac_tflops / FP64_MFMA_PEAK_TFLOPS, 4),
             "max_galerkin_last_sweep": None if eps is None else float(max(eps)),

@@ -78,6 +78,33 @@ class DevicePlumbing:
     def local_dAC(self, H, GLloc, GR, x):
         return self.be.dAC(H, GLloc, GR, x)
 
+    def row_block_tensor(self, A, lo, hi):
+        """rows [lo, hi) of the first index of A[a, s, b]  (column-major: a (Dl x d*Dr) matrix)."""
+        Dl, d, Dr = A.shape
+        n = hi - lo
+        out = self.be.empty(n, d, Dr)
+        self.be.copy2d(n, d * Dr, A.ptr + 8 * lo, Dl, out.ptr, n)
+        return out
+
+    def _all_reduce_flat(self, t, group):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
+    def all_reduce_sum(self, part, group, world):
+        self._all_reduce_flat(part.buf[: part.size], group)
+        return part
+
+    def all_gather_cols(self, cols, group, world):
+        """cols: (W, Dl, n) = the column block of this rank for every slab -> (W, Dl, n * world)."""
+        W, Dl, n = cols.shape
+        gathered = self._all_gather_flat(cols, group, world)
+        out = self.be.empty(W, Dl, n * world)
+        for p in range(world):   # rank p, slab w: a contiguous Dl*n chunk -> columns [p*n, (p+1)*n) of slab w
+            self.be.copy2d(Dl * n, W, gathered.data_ptr() + 8 * p * cols.size, Dl * n,
+                           out.ptr + 8 * p * Dl * n, Dl * n * world)
+        return out
+
     def _all_gather_flat(self, yloc, group, world):
         """the collective itself: rank blocks back to back in one device buffer (RCCL on the current stream)."""
         import torch
@@ -95,6 +122,50 @@ class DevicePlumbing:
         return y
 
 
+class ShardedTransfer:
+    """Environment updates with the compute sharded over the process group ("A only where the
+    contraction index must be split (env updates with sharded AL)").  Storage stays replicated in this version.
+
+    transfer_left :  GL'[v][b', b] = sum_{a', s', a, s, w} Ab[a', s', b'] GL[w][a', a] A[a, s, b] O[w, s', s, v].
+        Rank p takes the rows a' in its block of GL AND of Ab (all three stages shrink by 1/P) -> a partial GL'
+        of full shape; ONE all-reduce (sum) completes it on every rank.
+    transfer_right:  GR'[w][a, a'] = sum A[a, s, b] GR[v][b, b'] Ab[a', s', b'] O[w, s, s', v].
+        Rank p takes the rows a' in its block of Ab -> the COLUMNS a'_p of every output slab, no reduction;
+        ONE all-gather of the column blocks + a device re-interleave completes GR'.
+    Both leave bit-identical environments on every rank (the collectives return the same bits everywhere)."""
+
+    def __init__(self, plumbing, world, rank, group=None, min_block=64, force=False):
+        self.pl, self.be = plumbing, plumbing.be
+        self.world, self.rank, self.group, self.min_block, self.force = world, rank, group, min_block, force
+        self.n_collectives = 0
+
+    def _ok(self, D):
+        return BondShard.shardable(D, self.world, self.min_block, self.force)
+
+    def transfer_left(self, H, GLin, A, Ab):
+        be = self.be
+        Dlb = Ab.shape[0]
+        if H is None or not self._ok(Dlb):
+            return be.transfer_left(H, GLin, A, Ab)
+        sh = BondShard(Dlb, self.world, self.rank)
+        GLloc = self.pl.row_block(GLin, sh.lo, sh.hi)                       # (W, Dlo, Dl)
+        Abloc = self.pl.row_block_tensor(Ab, sh.lo, sh.hi)                  # (Dlo, d, Drb)
+        part = be.transfer_left(H, GLloc, A, Abloc)
+        self.n_collectives += 1
+        return self.pl.all_reduce_sum(part, self.group, self.world)
+
+    def transfer_right(self, H, GRin, A, Ab):
+        be = self.be
+        Dlb = Ab.shape[0]
+        if H is None or not self._ok(Dlb):
+            return be.transfer_right(H, GRin, A, Ab)
+        sh = BondShard(Dlb, self.world, self.rank)
+        Abloc = self.pl.row_block_tensor(Ab, sh.lo, sh.hi)
+        cols = be.transfer_right(H, GRin, A, Abloc)                         # (W, Dl, Dlo): columns a'_p
+        self.n_collectives += 1
+        return self.pl.all_gather_cols(cols, self.group, self.world)
+
+
 class HostStagedPlumbing(DevicePlumbing):
     """DevicePlumbing whose collective is staged through the host over gloo: lets TWO ranks share ONE GPU (RCCL
     refuses duplicate devices), so the device-side row-block extraction and re-interleave are exercised at
@@ -107,6 +178,13 @@ class HostStagedPlumbing(DevicePlumbing):
         outs = [torch.empty_like(h) for _ in range(world)]
         dist.all_gather(outs, h, group=group)
         return torch.cat(outs).to(self.be.device)
+
+    def _all_reduce_flat(self, t, group):
+        import torch.distributed as dist
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h.to(t.device))
+        return t
 
 
 class ShardedMatvec:

@@ -77,7 +77,24 @@ def _worker(rank, world, port, ret):
         outs = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(outs, t)
         ok_c = abs(Es - Eu) < 1e-10 * abs(Eu) and all(float(o) == Es for o in outs)
-        ret[rank] = (ok_a, ok_b, ok_c, Es, Eu)
+
+        # (d) sharded environment updates (dist.ShardedTransfer): all-reduce / all-gather versions == the kernels,
+        #     and a sweep whose FinEnv uses them stays in lock-step with the unsharded one
+        st = mdist.ShardedTransfer(mdist.DevicePlumbing(cb), world, rank, min_block=2)
+        A = cb.upload(rng.standard_normal((D, d, D)))
+        tl_s, tl_u = cb.download(st.transfer_left(Hg[1], dGL, A, A)), cb.download(cb.transfer_left(Hg[1], dGL, A, A))
+        tr_s, tr_u = cb.download(st.transfer_right(Hg[1], dGR, A, A)), cb.download(cb.transfer_right(Hg[1], dGR, A, A))
+        ok_d = bool(np.abs(tl_s - tl_u).max() < 1e-12 * np.abs(tl_u).max() and np.abs(tr_s - tr_u).max() < 1e-12 * np.abs(tr_u).max())
+        ok_d = ok_d and st.n_collectives == 2
+        pd = mk.FiniteMPS(As, normalize=True, be=cb)
+        ed = mk.FinEnv(pd, Hg, transfer_ops=st)
+        for _ in range(3):
+            alg.dmrg_sweep(pd, Hg, ed, eig, krylov.KrylovWorkspace(cb), wrap)
+        Ed = float(np.sum(mk.expectation_value(pd, Hg, ed)))
+        t = torch.tensor([Ed], dtype=torch.float64)
+        dist.all_gather(outs, t)
+        ok_d = ok_d and abs(Ed - Eu) < 1e-10 * abs(Eu) and all(float(o) == Ed for o in outs)
+        ret[rank] = (ok_a, ok_b, ok_c and ok_d, Es, Eu)
     finally:
         dist.destroy_process_group()
 

@@ -27,13 +27,22 @@ ps = psi.copy()
 eig = mk.Arnoldi(fixed_matvecs=4, krylovdim=4)
 alg.dmrg_sweep(psi, H, mk.FinEnv(psi, H), eig, krylov.KrylovWorkspace(be))
 alg.dmrg_sweep(ps, H, mk.FinEnv(ps, H), eig, krylov.KrylovWorkspace(be), md.shard_wrapper(be, world, rank, None, 32, plumbing=pl))
+# sharded environment updates (all-reduce / all-gather + device re-interleave)
+st = md.ShardedTransfer(pl, world, rank, None, 32)
+A = be.upload(rng.standard_normal((D, d, D)))
+tl_s, tl_u = be.download(st.transfer_left(H[1], GL, A, A)), be.download(be.transfer_left(H[1], GL, A, A))
+tr_s, tr_u = be.download(st.transfer_right(H[1], GR, A, A)), be.download(be.transfer_right(H[1], GR, A, A))
+err_t = max(np.abs(tl_s - tl_u).max() / np.abs(tl_u).max(), np.abs(tr_s - tr_u).max() / np.abs(tr_u).max())
+pt = mk.FiniteMPS.random(L, 2, Dm, np.random.default_rng(1), be=be)
+alg.dmrg_sweep(pt, H, mk.FinEnv(pt, H, transfer_ops=st), eig, krylov.KrylovWorkspace(be), md.shard_wrapper(be, world, rank, None, 32, plumbing=pl))
+e3 = float(np.sum(mk.expectation_value(pt, H, mk.FinEnv(pt, H))))
 e1 = float(np.sum(mk.expectation_value(psi, H, mk.FinEnv(psi, H))))
 e2 = float(np.sum(mk.expectation_value(ps, H, mk.FinEnv(ps, H))))
 t = torch.tensor([e2], dtype=torch.float64)
 lst = [torch.zeros_like(t) for _ in range(world)]
 dist.all_gather(lst, t)
 spread = max(abs(float(a) - e2) for a in lst)
-ok = err < 1e-13 and abs(e1 - e2) < 1e-10 * abs(e1) and spread == 0.0
-print(f"rank {rank}: matvec relerr {err:.2e}, sweep energy {e1:.12f} vs sharded {e2:.12f}, spread {spread:.1e} -> {'OK' if ok else 'FAIL'}", flush=True)
+ok = err < 1e-13 and err_t < 1e-13 and abs(e1 - e2) < 1e-10 * abs(e1) and abs(e1 - e3) < 1e-10 * abs(e1) and spread == 0.0 and st.n_collectives > 2
+print(f"rank {rank}: matvec relerr {err:.2e}, transfer relerr {err_t:.2e}, sharded-env sweep {e3:.12f}, sweep energy {e1:.12f} vs sharded {e2:.12f}, spread {spread:.1e} -> {'OK' if ok else 'FAIL'}", flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
