@@ -130,8 +130,9 @@ def tsvd(be):
 def main():
     be = mk.Backend(0)
     which = sys.argv[1:] or ["c2", "c3", "c4", "tsvd"]
-    for w in which:
-        globals()[w](be)
+    for w in which:                       # name[:int args], e.g. c4sweep:16:1024
+        name, *a = w.split(":")
+        globals()[name](be, *[int(v) for v in a])
 
 
 main()
