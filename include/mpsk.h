@@ -144,6 +144,14 @@ int mpsk_lqpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* L, int
  * ||S_dropped||_2 <= trunc_err * ||S||_2.  *kept / *disc_norm are written on the host (sync). */
 int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, int ldu, void* S, void* Vh,
               int ldv, int max_keep, double trunc_err, int* kept, double* disc_norm);
+/* Truncated two-site split theta (m x n, min(m, n) > 64) ~ AL (m x k) . C (k x k) . AR (k x n): what dmrg.jl:96-104 /
+ * tdvp.jl:124-126 build from tsvd! (al, c, ar), with the same truncation arguments as mpsk_tsvd, but computed without
+ * accumulating the Jacobi rotations (a third less memory traffic per round): AL, AR are isometries to rounding,
+ * AL C AR = theta projected on the kept singular subspace, C is triangular (upper if m >= n, lower otherwise) instead
+ * of diag(S); S (min(m, n) doubles) receives all singular values, *kept = k.
+ * Buffers: AL m x min(m,n), C min(m,n)^2, AR min(m,n) x n (only the leading k columns / rows are written). */
+int mpsk_tsplit(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
+                void* AL, int ldal, void* C, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm);
 /* general column-major product C = alpha op(A) op(B) + beta C for the small gauge products
  * AC = AL*C, AC = C*AR, theta = AC*AR, AL = Q_AC*Q_C'  (orthoview.jl:99,103; dmrg.jl:92; ortho.jl:130) */
 int mpsk_gemm(mpsk_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const void* A,

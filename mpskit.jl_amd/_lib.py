@@ -66,6 +66,8 @@ SIGNATURES = {
     "mpsk_lqpos": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
     "mpsk_tsvd": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                   C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p],
+    "mpsk_tsplit": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), c_double_p],
     "mpsk_gemm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
                   C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64],
     "mpsk_copy2d": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],

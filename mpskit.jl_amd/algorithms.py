@@ -258,24 +258,16 @@ def _dmrg2(psi, H, alg: DMRG2, envs=None):  # dmrg.jl:80-137
             rec = be.gemm(t, arm)
             v = be.dot(ac2, DTensor(rec.buf, ac2.shape)) / 2.0
             return al, c, ar, abs(1 - abs(v))
-        U, S, Vh, kept, _ = be.tsvd(new.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
-        k = kept
-        # normalize!(c)
-        Sk = DTensor(S.buf, (k,))
-        be.scal(1.0 / be.norm(Sk), Sk)
-        s_host = be.download(Sk)
-        c = be.upload(np.diag(s_host))
-        al = DTensor(U.buf, (Dl, d1, k))                      # first k columns of U (ld = Dl*d1)
-        # ar[k, s2, b] = Vh[k, b, s2] : d2 strided copies out of Vh (ld = kmax)
-        kmax = Vh.shape[0]
-        ar = be.empty(k, d2, Dr)
+        alm, c, arm, _, _ = be.tsplit(new.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
+        k = c.shape[0]
+        be.scal(1.0 / be.norm(c), c)                            # normalize!(c)  (|c|_F = |S_kept|)
+        al = alm.reshape(Dl, d1, k)
+        ar = be.empty(k, d2, Dr)                                # ar[k, s2, b] = arm[k, (b, s2)]
         for s2 in range(d2):
-            be.copy2d(k, Dr, Vh.ptr + 8 * s2 * kmax * Dr, kmax, ar.ptr + 8 * s2 * k, k * d2)
+            be.copy2d(k, Dr, arm.ptr + 8 * s2 * k * Dr, k, ar.ptr + 8 * s2 * k, k * d2)
         # fidelity  v = <ac2, al c ar>   (dmrg.jl:98-100)
-        us = be.gemm(al.reshape(Dl * d1, k), c)
-        rec = be.empty(Dl, d1, Dr, d2)
-        be.gemm_raw(False, False, Dl * d1, Dr * d2, k, 1.0, us.ptr, Dl * d1, Vh.ptr, kmax, 0.0, rec.ptr, Dl * d1)
-        v = be.dot(ac2, rec)
+        rec = be.gemm(be.gemm(alm, c), arm)
+        v = be.dot(ac2, DTensor(rec.buf, ac2.shape))
         return al, c, ar, abs(1 - abs(v))
 
     for it in range(1, alg.maxiter + 1):
@@ -425,14 +417,12 @@ def _split_two_site(be, nac2, alg, cx=False):
         al, c, ar, _, _ = split_two_site(be, nac2, alg.trunc_dim, alg.trunc_err if alg.trunc_dim <= 0 else 0.0)
         return al, c, ar
     trunc_err = alg.trunc_err if alg.trunc_dim <= 0 else 0.0
-    U, S, Vh, k, _ = be.tsvd(nac2.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
-    c = be.upload(np.diag(be.download(DTensor(S.buf, (k,)))))
-    al = DTensor(U.buf, (Dl, d1, k))
-    kmax = Vh.shape[0]
+    alm, c, arm, _, _ = be.tsplit(nac2.reshape(Dl * d1, Dr * d2), max_keep=alg.trunc_dim, trunc_err=trunc_err)
+    k = c.shape[0]
     ar = be.empty(k, d2, Dr)
     for s2 in range(d2):
-        be.copy2d(k, Dr, Vh.ptr + 8 * s2 * kmax * Dr, kmax, ar.ptr + 8 * s2 * k, k * d2)
-    return al, c, ar
+        be.copy2d(k, Dr, arm.ptr + 8 * s2 * k * Dr, k, ar.ptr + 8 * s2 * k, k * d2)
+    return alm.reshape(Dl, d1, k), c, ar
 
 
 def _timestep_tdvp2(psi, H, t, dt, alg: TDVP2, envs):  # tdvp.jl:113-146

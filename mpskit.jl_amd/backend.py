@@ -281,6 +281,31 @@ class Backend:
                                  float(trunc_err), C.byref(kept), C.byref(disc)), "mpsk_tsvd")
         return U, S, Vh, kept.value, disc.value
 
+    def tsplit(self, theta: DTensor, max_keep=0, trunc_err=0.0):
+        """Truncated two-site split theta (m x n) ~ al (m x k) . c (k x k) . ar (k x n)  (mpsk_tsplit: V-free Jacobi;
+        small tensors go through mpsk_tsvd with c = diag(S)).  Returns (al, c, ar, S[:k] on the host, disc)."""
+        m, n = theta.shape
+        kmax = min(m, n)
+        if kmax <= 64:
+            U, S, Vh, k, disc = self.tsvd(theta, max_keep=max_keep, trunc_err=trunc_err)
+            s = self.download(DTensor(S.buf, (k,)))
+            al = self.empty(m, k)
+            self.copy2d(m, k, U.ptr, m, al.ptr, m)
+            ar = self.empty(k, n)
+            self.copy2d(k, n, Vh.ptr, kmax, ar.ptr, k)
+            return al, self.upload(np.diag(s)), ar, s, disc
+        AL, Cm, AR, S = self.empty(m, kmax), self.empty(kmax, kmax), self.empty(kmax, n), self.empty(kmax)
+        kept, disc = C.c_int(0), C.c_double(0.0)
+        check(self.lib.mpsk_tsplit(self.ctx, m, n, theta.ptr, m, int(max_keep), float(trunc_err), AL.ptr, m, Cm.ptr, kmax,
+                                   AR.ptr, kmax, S.ptr, C.byref(kept), C.byref(disc)), "mpsk_tsplit")
+        k = kept.value
+        al = DTensor(AL.buf, (m, k))                       # leading k columns, ld = m
+        c = self.empty(k, k)
+        self.copy2d(k, k, Cm.ptr, kmax, c.ptr, k)
+        ar = self.empty(k, n)
+        self.copy2d(k, n, AR.ptr, kmax, ar.ptr, k)
+        return al, c, ar, self.download(DTensor(S.buf, (k,))), disc.value
+
     # ---- vectors -----------------------------------------------------------------------------
     def _ptrs(self, xs):
         arr = (C.c_void_p * len(xs))(*[x.ptr for x in xs])

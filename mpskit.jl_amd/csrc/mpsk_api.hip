@@ -688,6 +688,67 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
   return MPSK_OK;
 }
 
+// Truncated two-site split  theta ~ AL . C . AR  (tsvd!(theta; trunc) followed by al, c, ar of dmrg.jl:96-104 /
+// tdvp.jl:124-126) WITHOUT accumulating the Jacobi rotations: QRpos of the tall orientation, V-free block Jacobi on
+// R^T -> singular values and the singular vectors of ONE side (exact, orthonormal); the other factor is rebuilt from
+// theta itself and re-orthonormalised by QRpos / LQpos, so AL, AR are isometries to rounding and
+// AL C AR = theta projected on the kept singular subspace; C is triangular instead of diag(S) (S is returned too).
+int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
+                void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
+  REQUIRE(c && theta && AL && Cm && AR && S && kept && disc_norm, "NULL argument");
+  REQUIRE(m > 0 && n > 0, "dimensions must be positive");
+  const int mm = m < n ? n : m, nn = m < n ? m : n, transposed = m < n ? 1 : 0;
+  REQUIRE(nn > 64, "mpsk_tsplit needs min(m, n) > 64 (use mpsk_tsvd for small tensors)");
+  REQUIRE(ldt >= m && ldal >= m && ldc >= 1 && ldar >= 1, "leading dimension too small");
+  REQUIRE(trunc_err >= 0.0, "trunc_err must be >= 0");
+  HIPCHK(hipSetDevice(c->device));
+  const auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);
+  const size_t need = sizeof(double) * (a_d + q_d + 2 * r_d + 8);
+  if (c->ws3_bytes < need) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    if (c->ws3) HIPCHK(hipFree(c->ws3));
+    c->ws3 = nullptr; c->ws3_bytes = 0;
+    if (hipMalloc(&c->ws3, need) != hipSuccess) return fail(MPSK_ERR_NOMEM, "mpsk_tsplit: workspace hipMalloc failed");
+    c->ws3_bytes = need;
+  }
+  double* At = (double*)c->ws3;            // theta^T when m < n
+  double* Qb = At + a_d;                   // Q of the preconditioning, later theta * Y_k / Y_k^T theta
+  double* Rb = Qb + q_d;                   // R (nn x nn)
+  double* Y = Rb + r_d;                    // sorted, normalised singular vectors of the short side (nn x nn)
+  const double* Ap = (const double*)theta;
+  int lda = ldt;
+  if (transposed) {
+    HIPCHK(transpose((const double*)theta, ldt, m, n, At, mm, c->stream));
+    Ap = At; lda = mm;
+  }
+  const size_t qws = sizeof(double) * qr_ws_doubles(mm, nn), sws = tsvd_workspace_bytes(nn, nn);
+  if (int rc = ensure_ws(c, (qws > sws ? qws : sws) + 256)) return rc;
+  if (int rc = qrpos_dispatch(c, mm, nn, Ap, lda, Qb, mm, Rb, nn, (double*)c->ws)) return rc;
+  std::string err;
+  hipError_t e = tsvd(nn, nn, Rb, nn, Y, nn, (double*)S, nullptr, 1, max_keep, trunc_err, kept, disc_norm, c->ws, c->stream,
+                      &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, nullptr, /*vfree=*/1);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + hipGetErrorString(e));
+  const int k = *kept;
+  REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");
+  if (!transposed) {
+    // theta (m x n): Y_k = right singular vectors.  B = theta Y_k = U_k S_k ; AL C = QRpos(B) ; AR = Y_k^T
+    GemmArgs g = mk((const double*)theta, Y, Qb, m, k, n, ldt, nn, m);
+    HIPCHK(gemm_f64(g, c->stream));
+    if (int rc = mpsk_qrpos(c, m, k, Qb, m, AL, ldal, Cm, ldc)) return rc;
+    HIPCHK(transpose(Y, nn, n, k, (double*)AR, ldar, c->stream));
+  } else {
+    // theta (m x n), m < n: Y_k = left singular vectors = AL.  M = Y_k^T theta = S_k V_k^T ; C AR = LQpos(M)
+    HIPCHK(hipMemcpy2DAsync(AL, sizeof(double) * ldal, Y, sizeof(double) * nn, sizeof(double) * m, k,
+                            hipMemcpyDeviceToDevice, c->stream));
+    GemmArgs g = mk(Y, (const double*)theta, Qb, k, n, m, nn, ldt, k, 1, 0);
+    HIPCHK(gemm_f64(g, c->stream));
+    if (int rc = mpsk_lqpos(c, k, n, Qb, k, Cm, ldc, AR, ldar)) return rc;
+  }
+  return MPSK_OK;
+}
+
 int mpsk_ctx_set_svd_mode(mpsk_ctx* c, int precondition) {
   REQUIRE(c, "ctx is NULL");
   c->svd_precondition = precondition ? 1 : 0;

@@ -384,8 +384,17 @@ size_t tsvd_workspace_bytes(int m, int n) { return svd_plan(m, n).bytes; }
 hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
                 int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,
                 std::string* err, int* sweeps_out, const double* Qpre, int ldq, int q_rows, int outer_transposed,
-                hipStream_t s2) {
+                hipStream_t s2, int vfree) {
+  // vfree: theta := R (n x n) of a QR-preconditioned problem, Jacobi on R^T WITHOUT accumulating the rotations
+  // (a third of the per-round traffic): returns S and, in U (n x kmax, ldu), the normalised sorted columns of the
+  // converged G = R^T W, i.e. the RIGHT singular vectors of R (and of the matrix R came from).  The caller rebuilds the
+  // other factor from the original matrix (mpsk_tsplit).
   SvdPlan pl = svd_plan(m, n);
+  if (vfree) {
+    if (m != n) return hipErrorInvalidValue;
+    pl.transposed = 1;
+    s2 = nullptr;
+  }
   if (Qpre) {
     if (m != n) return hipErrorInvalidValue;
     pl.transposed = 1;                    // G <- R^T
@@ -495,11 +504,13 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G; u.tabC = t_updC_G;
       u.tabC2 = t_updC_G + P;
       if ((e = gemm_f64(u, s)) != hipSuccess) { drop_events(); return e; }
-      if (s2 != s) (void)hipStreamWaitEvent(s2, evW[wb], 0);
-      u.A = V[vcur]; u.C = V[vcur ^ 1]; u.M = nn; u.lda = nn; u.ldc = nn; u.tabA = t_updA_V; u.tabC = t_updC_V;
-      u.tabC2 = t_updC_V + P;
-      if ((e = gemm_f64(u, s2)) != hipSuccess) { drop_events(); return e; }
-      if (s2 != s) (void)hipEventRecord(evV[wb], s2);
+      if (!vfree) {
+        if (s2 != s) (void)hipStreamWaitEvent(s2, evW[wb], 0);
+        u.A = V[vcur]; u.C = V[vcur ^ 1]; u.M = nn; u.lda = nn; u.ldc = nn; u.tabA = t_updA_V; u.tabC = t_updC_V;
+        u.tabC2 = t_updC_V + P;
+        if ((e = gemm_f64(u, s2)) != hipSuccess) { drop_events(); return e; }
+        if (s2 != s) (void)hipEventRecord(evV[wb], s2);
+      }
       cur ^= 1;
       vcur ^= 1;
     }
@@ -548,7 +559,9 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   if ((e = hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(scale, sc.data(), sizeof(double) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(S, sv.data(), sizeof(double) * kmax, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
-  if (Qpre) {
+  if (vfree) {
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, G[cur], mm, nn, d_perm, scale, kmax, U, ldu, 0);
+  } else if (Qpre) {
     double* Vp = G[cur ^ 1];              // the idle ping-pong buffer holds W[:, perm]  (n x kmax)
     hipLaunchKernelGGL(gather_cols_kernel, dim3(1024), dim3(256), 0, s, V[cur], nn, nn, d_perm, (const double*)nullptr,
                        kmax, Vp, nn, 0);

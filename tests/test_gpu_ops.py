@@ -409,3 +409,26 @@ def test_qrlq_pair(be, m, n):
     Qs, Rs = (be.download(t) for t in be.qrpos(be.upload(A1)))
     Ls, Qls = (be.download(t) for t in be.lqpos(be.upload(A2)))
     assert relerr(Q1, Qs) < 1e-12 and relerr(L2, Ls) < 1e-11 and relerr(Q2, Qls) < 1e-10
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 384, 100), (384, 512, 100), (1024, 1024, 256), (200, 130, 0)])
+def test_tsplit(be, m, n, k):
+    """mpsk_tsplit (V-free Jacobi + rebuilt factor): al, ar isometries, al c ar = the optimal rank-k truncation of theta
+    (same singular values / discarded norm as numpy), c triangular, for both orientations and a graded spectrum."""
+    rng = np.random.default_rng(m + 3 * n + k)
+    r = min(m, n)
+    Uo, _ = np.linalg.qr(rng.standard_normal((m, r)))
+    Vo, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    s = np.logspace(0, -9, r)
+    A = (Uo * s) @ Vo.T
+    al, c, ar, S, disc = be.tsplit(be.upload(A), max_keep=k)
+    kk = k if k > 0 else r
+    al, c, ar = be.download(al), be.download(c), be.download(ar)
+    assert al.shape == (m, kk) and c.shape == (kk, kk) and ar.shape == (kk, n)
+    assert np.abs(S - s[:kk]).max() < 1e-13
+    assert abs(disc - np.linalg.norm(s[kk:])) < 1e-13
+    assert np.abs(al.T @ al - np.eye(kk)).max() < 1e-12 and np.abs(ar @ ar.T - np.eye(kk)).max() < 1e-12
+    best = (Uo[:, :kk] * s[:kk]) @ Vo[:, :kk].T
+    assert np.abs(al @ c @ ar - best).max() < 1e-12
+    assert np.abs(np.linalg.svd(c, compute_uv=False) - s[:kk]).max() < 1e-13
+    assert np.abs(np.tril(c, -1)).max() < 1e-13 or np.abs(np.triu(c, 1)).max() < 1e-13

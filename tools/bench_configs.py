@@ -66,7 +66,7 @@ def c4sweep(be, L=16, D=256):
     H = mk.hubbard(1.0, 4.0, be=be)
     psi = mk.FiniteMPS.random(L, 4, D, np.random.default_rng(3), be=be)
     stat = {"svd_s": 0.0, "svd_n": 0, "sweeps": [], "eig_s": 0.0}
-    orig_tsvd, orig_fp = be.tsvd, alg.fixedpoint
+    orig_tsvd, orig_fp = be.tsplit, alg.fixedpoint
 
     def tsvd_timed(*a, **k):
         sync(); t0 = time.perf_counter()
@@ -81,7 +81,7 @@ def c4sweep(be, L=16, D=256):
         sync(); stat["eig_s"] += time.perf_counter() - t0
         return out
 
-    be.tsvd, alg.fixedpoint = tsvd_timed, fp_timed
+    be.tsplit, alg.fixedpoint = tsvd_timed, fp_timed
     try:
         for it in range(2):
             for k in stat:
@@ -97,7 +97,7 @@ def c4sweep(be, L=16, D=256):
                   f"({stat['svd_n']} calls, Jacobi sweeps min/mean/max {min(sw)}/{np.mean(sw):.1f}/{max(sw)}), "
                   f"qr +{ {k: q1[k] - q0[k] for k in q1} }, max bond {max(psi.bond_dims())}", flush=True)
     finally:
-        be.tsvd, alg.fixedpoint = orig_tsvd, orig_fp
+        be.tsplit, alg.fixedpoint = orig_tsvd, orig_fp
 
 
 def ctdvp(be, L=32, D=128):
