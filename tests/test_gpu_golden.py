@@ -94,3 +94,31 @@ def test_full_size_properties(be):
     out = be.transfer_left(None, one, AL, AL)
     be.axpby(-1.0, eye, 1.0, mk.DTensor(out.buf, (D, D)))
     assert be.norm(mk.DTensor(out.buf, (D, D))) < 1e-11
+
+
+def test_full_size_two_site_split_properties(be):
+    """Size-independent identities of mpsk_tsplit at the config-4 tensor size (theta 4096 x 4096, keep 1024): al / ar
+    isometries, |theta|^2 = |c|^2 + discarded^2 (Pythagoras for an orthogonal projection on singular subspaces), c
+    triangular with the Schmidt values as singular values, al c ar = al al^T theta (projection on the kept LEFT subspace)."""
+    import torch
+    n, k = 4096, 1024
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.rand(n, n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    A = A * torch.logspace(0, -6, n, dtype=torch.float64, device="cuda")[None, :]        # graded columns
+    from mpskit_jl_amd import DTensor
+    th = DTensor(A.T.contiguous().flatten(), (n, n))                                     # column-major copy of A
+    al, c, ar, S, disc = be.tsplit(th, max_keep=k)
+    alT = torch.as_strided(al.buf, (n, k), (1, n))
+    arT = torch.as_strided(ar.buf, (k, n), (1, k))
+    cT = torch.as_strided(c.buf, (k, k), (1, k))
+    eye = torch.eye(k, dtype=torch.float64, device="cuda")
+    assert float((alT.T @ alT - eye).abs().max()) < 1e-12
+    assert float((arT @ arT.T - eye).abs().max()) < 1e-12
+    tot2 = float((A * A).sum())
+    assert abs(tot2 - float((cT * cT).sum()) - disc ** 2) < 1e-11 * tot2
+    assert abs(float((cT * cT).sum()) - float(np.sum(S ** 2))) < 1e-11 * tot2
+    assert float(torch.tril(cT, -1).abs().max()) == 0.0
+    proj = alT @ (alT.T @ A)
+    assert float((alT @ cT @ arT - proj).abs().max()) < 1e-11 * float(A.abs().max())
+    sv = torch.linalg.svdvals(cT).cpu().numpy()
+    assert np.abs(sv - S).max() < 1e-12 * S[0]
