@@ -60,6 +60,18 @@ __device__ __forceinline__ double cq_readlane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(x) and sqrt(x) for a pivot on the serial critical path of the 64-step elimination: v_rsq_f64 seed (~2^-26)
+// + two Newton steps (full fp64) instead of the IEEE sqrt + division sequences (~50 dependent instructions a pivot).
+__device__ __forceinline__ void piv_rsqrt(double x, double* rs_out, double* sq_out) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  double s = x * r;
+  s = s + 0.5 * r * (x - s * s);            // one correction: s = sqrt(x) to the last bit or two
+  *rs_out = r;
+  *sq_out = s;
+}
+
 // ---- fused right-looking Cholesky step --------------------------------------------------------------
 // One launch per 64-column block k (instead of potrf + trsm + syrk = three dependent launches):
 //   * trailing tiles (i, j), k <= i <= j:  G_ij -= Y_i^T Y_j with Y_x = R_{k-1,k-1}^-T G_{k-1,x} formed in the tile
@@ -244,8 +256,10 @@ __global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, do
         const double piv = cq_readlane(p[t], j0 + t);
         const bool ok = (piv > 0.0) && (piv < 1.0e300);
         if (!ok) bad = 1;
-        const double sq = ok ? sqrt(piv) : 1.0;
-        const double rs = ok ? 1.0 / sq : 0.0;
+        double rs_, sq_;
+        piv_rsqrt(ok ? piv : 1.0, &rs_, &sq_);
+        const double sq = ok ? sq_ : 1.0;
+        const double rs = ok ? rs_ : 0.0;
         p[t] = (lane > j0 + t) ? p[t] * rs : (lane == j0 + t ? sq : 0.0);
         e[t] *= rs;
 #pragma unroll

@@ -36,6 +36,18 @@ __device__ __forceinline__ double sv_readlane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(x) and sqrt(x) for a pivot on the serial critical path of the 64-step elimination: v_rsq_f64 seed (~2^-26)
+// + two Newton steps (full fp64) instead of the IEEE sqrt + division sequences (~50 dependent instructions a pivot).
+__device__ __forceinline__ void sv_piv_rsqrt(double x, double* rs_out, double* sq_out) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  double s = x * r;
+  s = s + 0.5 * r * (x - s * s);            // one correction: s = sqrt(x) to the last bit or two
+  *rs_out = r;
+  *sq_out = s;
+}
+
 __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restrict__ Mpart, int Q,
                                                          double* __restrict__ Wout, double tol,
                                                          unsigned long long* __restrict__ flag, int inner_sweeps) {
@@ -148,8 +160,10 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
         for (int t = 0; t < 4; ++t) {
           const double piv = sv_readlane(pr[t], j0 + t);
           const bool ok = (piv > ptol) && (piv < 1.0e300);     // semi-definite: a vanishing pivot zeroes the row
-          const double sq = ok ? sqrt(piv) : 0.0;
-          const double rs = ok ? 1.0 / sq : 0.0;
+          double rs_, sq_;
+          sv_piv_rsqrt(ok ? piv : 1.0, &rs_, &sq_);
+          const double sq = ok ? sq_ : 0.0;
+          const double rs = ok ? rs_ : 0.0;
           pr[t] = (lane > j0 + t) ? pr[t] * rs : (lane == j0 + t ? sq : 0.0);
 #pragma unroll
           for (int u = t + 1; u < 4; ++u) pr[u] -= sv_readlane(pr[t], j0 + u) * pr[t];
