@@ -483,7 +483,8 @@ int mpsk_regularize(mpsk_ctx* c, int W, int D1, int D2, void* v, const void* lve
   REQUIRE(c && v && lvec && rvec, "NULL argument");
   REQUIRE(W > 0 && D1 > 0 && D2 > 0, "dimensions must be positive");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(regularize(W, D1, D2, (double*)v, (const double*)lvec, (const double*)rvec, c->stream));
+  if (int rc = ensure_ws(c, sizeof(double) * regularize_workspace_doubles(W, D1, D2))) return rc;
+  HIPCHK(regularize(W, D1, D2, (double*)v, (const double*)lvec, (const double*)rvec, (double*)c->ws, c->stream));
   return MPSK_OK;
 }
 

@@ -7,29 +7,64 @@
 
 namespace mpsk {
 
-// v[w] -= <lvec^T, v[w]> rvec      (transfermatrix.jl:70-76); one workgroup per slab
-__global__ __launch_bounds__(256) void regularize_kernel(double* __restrict__ v, const double* __restrict__ lvec,
-                                                         const double* __restrict__ rvec, int D1, int D2) {
+// v[w] -= <lvec^T, v[w]> rvec      (transfermatrix.jl:70-76): coef_w = sum_{x,y} lvec[x, y] v_w[y, x].
+// Phase 1: one workgroup per 32 x 32 tile of a slab; the lvec tile is read coalesced along x and transposed through LDS
+// so that the v tile is read coalesced along y (the single-workgroup, stride-D2 version this replaces took 3 ms per
+// 1024 x 1024 slab -- the dominant cost of every GMRES step on the regularised transfer matrix).
+// Phase 2: every workgroup sums the tile partials of its slab in the same order (deterministic) and updates its chunk.
+constexpr int RG_T = 32;
+__global__ __launch_bounds__(256) void regularize_dot_kernel(const double* __restrict__ v, const double* __restrict__ lvec,
+                                                             double* __restrict__ partial, int D1, int D2, int tx_n) {
+  __shared__ double tile[RG_T][RG_T + 1];
   __shared__ double sh[4];
-  __shared__ double coef;
-  double* vw = v + (int64_t)blockIdx.x * D1 * D2;
+  const int t = blockIdx.x, w = blockIdx.y;
+  const int x0 = (t % tx_n) * RG_T, y0 = (t / tx_n) * RG_T;      // v[y, x], y in [0, D1), x in [0, D2); lvec[x, y] (D2 x D1)
+  const double* vw = v + (int64_t)w * D1 * D2;
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;         // 8 rows of 32 threads
+  for (int r = r0; r < RG_T; r += 8) {                           // lvec tile: fast index x
+    const int x = x0 + c, y = y0 + r;
+    tile[r][c] = (x < D2 && y < D1) ? lvec[x + (int64_t)D2 * y] : 0.0;
+  }
+  __syncthreads();
   double acc = 0.0;
-  const int64_t n = (int64_t)D1 * D2;
-  for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
-    int y = (int)(e % D1), x = (int)(e / D1);   // v[y, x]
-    acc += lvec[x + (int64_t)D2 * y] * vw[e];
+  for (int r = r0; r < RG_T; r += 8) {                           // v tile: fast index y
+    const int y = y0 + c, x = x0 + r;
+    if (x < D2 && y < D1) acc += tile[c][r] * vw[y + (int64_t)D1 * x];
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) coef = sh[0] + sh[1] + sh[2] + sh[3];
-  __syncthreads();
-  const double cf = coef;
-  for (int64_t e = threadIdx.x; e < n; e += blockDim.x) vw[e] -= cf * rvec[e];
+  if (threadIdx.x == 0) partial[(int64_t)w * gridDim.x + t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-hipError_t regularize(int W, int D1, int D2, double* v, const double* lvec, const double* rvec, hipStream_t s) {
-  hipLaunchKernelGGL(regularize_kernel, dim3(W), dim3(256), 0, s, v, lvec, rvec, D1, D2);
+__global__ __launch_bounds__(256) void regularize_apply_kernel(double* __restrict__ v, const double* __restrict__ rvec,
+                                                               const double* __restrict__ partial, int ntiles, int64_t n) {
+  __shared__ double sh[4];
+  __shared__ double coef;
+  const int w = blockIdx.y;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < ntiles; i += 256) acc += partial[(int64_t)w * ntiles + i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) coef = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  const double cf = coef;
+  double* vw = v + (int64_t)w * n;
+  for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) vw[e] -= cf * rvec[e];
+}
+
+size_t regularize_workspace_doubles(int W, int D1, int D2) {
+  return (size_t)W * ((D1 + RG_T - 1) / RG_T) * ((D2 + RG_T - 1) / RG_T);
+}
+
+hipError_t regularize(int W, int D1, int D2, double* v, const double* lvec, const double* rvec, double* partial, hipStream_t s) {
+  const int tx_n = (D2 + RG_T - 1) / RG_T, ty_n = (D1 + RG_T - 1) / RG_T, ntiles = tx_n * ty_n;
+  hipLaunchKernelGGL(regularize_dot_kernel, dim3(ntiles, W), dim3(256), 0, s, v, lvec, partial, D1, D2, tx_n);
+  const int64_t n = (int64_t)D1 * D2;
+  int nb = (int)((n + 2047) / 2048);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(regularize_apply_kernel, dim3(nb, W), dim3(256), 0, s, v, rvec, partial, ntiles, n);
   return hipGetLastError();
 }
 

@@ -81,7 +81,8 @@ hipError_t vec_multiaxpy(const double* const* xs, const double* d_coefs, int k, 
                          int64_t n, hipStream_t s);
 
 // ---- gauge kernels ----------------------------------------------------------------------------
-hipError_t regularize(int W, int D1, int D2, double* v, const double* lvec, const double* rvec, hipStream_t s);
+size_t regularize_workspace_doubles(int W, int D1, int D2);
+hipError_t regularize(int W, int D1, int D2, double* v, const double* lvec, const double* rvec, double* partial, hipStream_t s);
 hipError_t transpose(const double* in, int ldi, int rows, int cols, double* out, int ldo, hipStream_t s);
 size_t qrpos_workspace_doubles(int m, int n);
 hipError_t qrpos(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,

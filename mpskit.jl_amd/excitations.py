@@ -97,7 +97,32 @@ def _expval_projection(psi, op, envs):
     return out
 
 
-def excitations(H, alg: FiniteExcited, psi0: FiniteMPS, num=1, init=None):
+def excitations(H, alg, *args, **kw):
+    """excitations(H, alg, args...; num)  (excitation/excitations.jl) -> (energies, states), dispatching on `alg` and the
+    argument types the way the reference's methods do:
+      FiniteExcited:        excitations(H, alg, psi0::FiniteMPS; num, init)                     dmrgexcitation.jl:13-36
+      QuasiparticleAnsatz:  excitations(H, alg, momentum | momenta, psi::InfiniteMPS[, envs]; num)   quasiparticleexcitation.jl:84-125
+                            excitations(H, alg, psi::FiniteMPS[, envs]; num)                    :163-169
+                            excitations(H, alg, phi0::LeftGaugedQP[, envs]; num)                :39-53,127-143"""
+    from .quasiparticle import QuasiparticleAnsatz, LeftGaugedQP, excitations_qp, excitations_momenta
+    if isinstance(alg, FiniteExcited):
+        return _excitations_finite_excited(H, alg, *args, **kw)
+    if not isinstance(alg, QuasiparticleAnsatz):
+        raise TypeError(f"excitations: unknown algorithm {type(alg).__name__}")
+    if isinstance(args[0], LeftGaugedQP):
+        return excitations_qp(H, alg, *args, **kw)
+    if isinstance(args[0], FiniteMPS):
+        psi, rest = args[0], args[1:]
+        if getattr(psi, "cplx", False):
+            raise NotImplementedError("QuasiparticleAnsatz on complex (embedded) ground states")
+        rng = kw.pop("rng", None)
+        return excitations_qp(H, alg, LeftGaugedQP.random(psi, 0.0, rng), *rest, **kw)
+    if getattr(args[1], "cplx", False):
+        raise NotImplementedError("QuasiparticleAnsatz on complex (embedded) ground states")
+    return excitations_momenta(H, alg, *args, **kw)
+
+
+def _excitations_finite_excited(H, alg: FiniteExcited, psi0: FiniteMPS, num=1, init=None):
     """excitations(H, FiniteExcited(gsalg, weight), psi0; num) -> (energies, states)."""
     if getattr(psi0, "cplx", False):
         raise NotImplementedError("FiniteExcited on complex (embedded) states: the projector needs both |v> and i|v>")

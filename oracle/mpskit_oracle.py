@@ -1595,3 +1595,281 @@ def excitations_finite(H, psi0, num=1, weight=10.0, tol=1e-10, maxiter=30, krylo
         states.append(psi)
         ens.append(float(np.sum(expectation_value(psi, H, FinEnv(psi, H))).real))
     return ens, states[1:]
+
+
+# --------------------------------------------------------------------------------------
+# Quasiparticle excitations (src/states/quasiparticle_state.jl, src/environments/qpenv.jl,
+# src/algorithms/excitation/quasiparticleexcitation.jl, exci_transfer_system.jl)
+# Trivial charge sector: the utility leg of B has dimension 1 and is dropped, B[a, s, b].
+# --------------------------------------------------------------------------------------
+
+class LeftGaugedQP:
+    """quasiparticle_state.jl:8-17,33-46 : B[i] = VL[i] X[i] with AL[i]^dag VL[i] = 0.
+    `finite` selects FiniteQP (momentum ignored) vs InfiniteQP semantics."""
+
+    def __init__(self, left_gs, right_gs, VLs, Xs, momentum=0.0, finite=False):
+        self.left_gs, self.right_gs, self.VLs, self.Xs = left_gs, right_gs, VLs, Xs
+        self.momentum, self.finite = momentum, finite
+
+    @classmethod
+    def random(cls, rng, left_gs, right_gs=None, momentum=0.0, dtype=np.complex128):
+        right_gs = left_gs if right_gs is None else right_gs
+        finite = isinstance(left_gs, FiniteMPS)
+        n = len(left_gs)
+        ALs = [left_gs.AL(i) for i in range(n)] if finite else left_gs.AL
+        ARs = [right_gs.AR(i) for i in range(n)] if finite else right_gs.AR
+        VLs = [leftnull(a) for a in ALs]
+        Xs = []
+        for i in range(n):
+            shp = (VLs[i].shape[2], ARs[i].shape[2])
+            x = rng.random(shp)
+            if np.issubdtype(dtype, np.complexfloating):
+                x = x + 1j * rng.random(shp)
+            Xs.append(x.astype(dtype))
+        return cls(left_gs, right_gs, VLs, Xs, momentum, finite)
+
+    @property
+    def trivial(self):
+        return self.left_gs is self.right_gs
+
+    def __len__(self):
+        return len(self.Xs)
+
+    def B(self, i):  # Base.getindex  :95
+        return np.tensordot(self.VLs[i], self.Xs[i], axes=([2], [0]))
+
+    def with_Xs(self, Xs):
+        return LeftGaugedQP(self.left_gs, self.right_gs, self.VLs, Xs, self.momentum, self.finite)
+
+    def to_vector(self):
+        return np.concatenate([x.reshape(-1) for x in self.Xs])
+
+    def from_vector(self, v):
+        Xs, off = [], 0
+        for x in self.Xs:
+            Xs.append(np.asarray(v[off:off + x.size]).reshape(x.shape))
+            off += x.size
+        return self.with_Xs(Xs)
+
+
+def _qp_gs(phi):
+    n = len(phi)
+    if phi.finite:
+        return ([phi.left_gs.AL(i) for i in range(n)], [phi.right_gs.AR(i) for i in range(n)])
+    return phi.left_gs.AL, phi.right_gs.AR
+
+
+def _reg_bond(v, C):
+    """the tau-contractions of qpenv.jl:69-76 / regularize!(::MPOTensor, ::Bond, ::Bond) transfermatrix.jl:87-90
+    with a one-dimensional MPO leg:  v[:, w, :] -= <C, v[:, w, :]> C."""
+    coef = np.einsum("xwy,xy->w", v, np.conj(C))
+    return v - np.einsum("w,xy->xwy", coef, C)
+
+
+def _tsum(a, b):
+    return [x + y for x, y in zip(a, b)]
+
+
+def qp_environments_finite(phi, H, lenvs, renvs):
+    """environments(exci::FiniteQP, ham)  qpenv.jl:146-170.  lBs[s] / rBs[s]: B strictly left / right of site s."""
+    n = len(phi)
+    AL, AR = _qp_gs(phi)
+    dt = np.result_type(phi.Xs[0].dtype, AL[0].dtype)
+    lBs = [[np.zeros((AL[s].shape[0], H[s].chil[j], AR[s].shape[0]), dtype=dt) for j in range(H.odim)] for s in range(n)]
+    rBs = [[np.zeros((AL[s].shape[2], H[s].chir[j], AR[s].shape[2]), dtype=dt) for j in range(H.odim)] for s in range(n)]
+    for pos in range(n - 1):
+        lBs[pos + 1] = _tsum(transfer_left(lBs[pos], H[pos], AR[pos], AL[pos]),
+                             transfer_left(lenvs.leftenv(pos, phi.left_gs), H[pos], phi.B(pos), AL[pos]))
+    for pos in range(n - 1, 0, -1):
+        rBs[pos - 1] = _tsum(transfer_right(rBs[pos], H[pos], AL[pos], AR[pos]),
+                             transfer_right(renvs.rightenv(pos, phi.right_gs), H[pos], phi.B(pos), AR[pos]))
+    return lBs, rBs
+
+
+def _partial_transfer_left(v, H, AR, AL, upto):
+    """found[1:i] * TransferMatrix(AR, H[1:i,1:i], AL) through the unit cell; returns level `upto` (exci_transfer_system.jl:12-14)."""
+    for s in range(len(AR)):
+        out = []
+        for k in range(upto + 1):
+            acc = np.zeros((AL[s].shape[2], H[s].chir[k], AR[s].shape[2]), dtype=v[0].dtype)
+            for j in range(k + 1):
+                if H[s].contains(j, k):
+                    O = H[s].Os[(j, k)]
+                    acc = acc + (O * transfer_left_block(v[j], None, AR[s], AL[s]) if np.isscalar(O)
+                                 else transfer_left_block(v[j], O, AR[s], AL[s]))
+            out.append(acc)
+        v = out
+    return v[upto]
+
+
+def _partial_transfer_right(v, H, AL, AR, frm):
+    """TransferMatrix(AL, H[i:odim,i:odim], AR) * found[i:odim]; v indexed by absolute level (:51-53)."""
+    odim = H.odim
+    for s in range(len(AL) - 1, -1, -1):
+        out = [None] * odim
+        for j in range(frm, odim):
+            acc = np.zeros((AL[s].shape[0], H[s].chil[j], AR[s].shape[0]), dtype=v[frm].dtype)
+            for k in range(j, odim):
+                if H[s].contains(j, k):
+                    O = H[s].Os[(j, k)]
+                    acc = acc + (O * transfer_right_block(v[k], None, AL[s], AR[s]) if np.isscalar(O)
+                                 else transfer_right_block(v[k], O, AL[s], AR[s]))
+            out[j] = acc
+        v = out
+    return v[frm]
+
+
+def left_excitation_transfer_system(lB, H, phi, tol=1e-12, maxiter=100):
+    """exci_transfer_system.jl:1-41 : x = lB + e^{-ip n} x T_cell, level by level."""
+    n, odim, p = len(phi), H.odim, phi.momentum
+    AL, AR = _qp_gs(phi)
+    C = phi.right_gs.CR[n - 1]
+    ph = np.exp(-1j * p * n)
+    found = [np.zeros_like(x, dtype=np.complex128) for x in lB]
+    for i in range(odim):
+        start = ph * _partial_transfer_left(found[:i + 1], H, AR, AL, i)
+        if phi.trivial and H.isid(i):
+            start = _reg_bond(start, C)
+        found[i] = start + lB[i]
+        if all(H[s].contains(i, i) for s in range(n)):
+            isid = H.isid(i)
+
+            def op(x):
+                y = x
+                for s in range(n):
+                    O = None if isid else H[s].Os[(i, i)]
+                    if O is not None and np.isscalar(O):
+                        y = O * transfer_left_block(y, None, AR[s], AL[s])
+                    else:
+                        y = transfer_left_block(y, O, AR[s], AL[s])
+                if isid and phi.trivial:
+                    y = _reg_bond(y, C)
+                return x - ph * y
+            found[i] = gmres(op, found[i], found[i], tol=tol, maxiter=maxiter)
+    return found
+
+
+def right_excitation_transfer_system(rB, H, phi, tol=1e-12, maxiter=100):
+    """exci_transfer_system.jl:43-85."""
+    n, odim, p = len(phi), H.odim, phi.momentum
+    AL, AR = _qp_gs(phi)
+    C = phi.right_gs.CR[n - 1]
+    ph = np.exp(1j * p * n)
+    found = [np.zeros_like(x, dtype=np.complex128) for x in rB]
+    for i in range(odim - 1, -1, -1):
+        start = ph * _partial_transfer_right(found, H, AL, AR, i)
+        if phi.trivial and H.isid(i):
+            start = _reg_bond(start, C)
+        found[i] = start + rB[i]
+        if all(H[s].contains(i, i) for s in range(n)):
+            isid = H.isid(i)
+
+            def op(x):
+                y = x
+                for s in range(n - 1, -1, -1):
+                    O = None if isid else H[s].Os[(i, i)]
+                    if O is not None and np.isscalar(O):
+                        y = O * transfer_right_block(y, None, AL[s], AR[s])
+                    else:
+                        y = transfer_right_block(y, O, AL[s], AR[s])
+                if isid and phi.trivial:
+                    y = _reg_bond(y, C)
+                return x - ph * y
+            found[i] = gmres(op, found[i], found[i], tol=tol, maxiter=maxiter)
+    return found
+
+
+def qp_environments_infinite(phi, H, lenvs, renvs, tol=1e-12, maxiter=100):
+    """environments(exci::InfiniteQP, ham::MPOHamiltonian, lenvs, renvs)  qpenv.jl:55-144."""
+    n, odim, p = len(phi), H.odim, phi.momentum
+    AL, AR = _qp_gs(phi)
+    ids = [i for i in range(1, odim - 1) if H.isid(i)]
+    gs = phi.left_gs
+    eL, eR = np.exp(-1j * p), np.exp(1j * p)
+    lBs = [[np.zeros((AL[s].shape[0], H[s].chil[j], AR[s].shape[0]), dtype=np.complex128) for j in range(odim)] for s in range(n)]
+    rBs = [[np.zeros((AL[s].shape[2], H[s].chir[j], AR[s].shape[2]), dtype=np.complex128) for j in range(odim)] for s in range(n)]
+
+    def regl(v, pos):   # bond right of site pos
+        if phi.trivial:
+            for i in ids:
+                v[i] = _reg_bond(v[i], gs.CR[pos % n])
+        return v
+
+    for pos in range(n):                                                       # :66-79
+        nxt = _tsum(transfer_left(lBs[pos], H[pos], AR[pos], AL[pos]),
+                    transfer_left(lenvs.leftenv(pos, phi.left_gs), H[pos], phi.B(pos), AL[pos]))
+        lBs[(pos + 1) % n] = regl([eL * x for x in nxt], pos)
+    for pos in range(n - 1, -1, -1):                                           # :81-97
+        nxt = _tsum(transfer_right(rBs[pos], H[pos], AL[pos], AR[pos]),
+                    transfer_right(renvs.rightenv(pos, phi.right_gs), H[pos], phi.B(pos), AR[pos]))
+        rBs[(pos - 1) % n] = regl([eR * x for x in nxt], pos - 1)
+    lBs[0] = left_excitation_transfer_system(lBs[0], H, phi, tol, maxiter)     # :99-105
+    rBs[n - 1] = right_excitation_transfer_system(rBs[n - 1], H, phi, tol, maxiter)
+    cur = lBs[0]
+    for i in range(n - 1):                                                     # :107-123
+        cur = regl([eL * x for x in transfer_left(cur, H[i], AR[i], AL[i])], i)
+        lBs[i + 1] = _tsum(lBs[i + 1], cur)
+    cur = rBs[n - 1]
+    for i in range(n - 1, 0, -1):                                              # :124-141
+        cur = regl([eR * x for x in transfer_right(cur, H[i], AL[i], AR[i])], i - 1)
+        rBs[i - 1] = _tsum(rBs[i - 1], cur)
+    return lBs, rBs
+
+
+def qp_renormalization_energy(H, phi, lenvs, renvs):
+    """effective_excitation_renormalization_energy  quasiparticleexcitation.jl:330-362."""
+    def side(gs, envs):
+        out = []
+        for loc in range(len(phi)):
+            ac = gs.AC(loc) if phi.finite else gs.AC[loc]
+            out.append(np.vdot(ac, dAC(ac, H[loc], envs.leftenv(loc, gs), envs.rightenv(loc, gs))))
+        return np.array(out)
+    E = side(phi.left_gs, lenvs)
+    return E if phi.trivial else (E + side(phi.right_gs, renvs)) / 2
+
+
+def effective_excitation_hamiltonian(H, phi, lenvs, renvs, energy, tol=1e-12):
+    """effective_excitation_hamiltonian + _effective_excitation_local_apply  :254-328; returns the new X's."""
+    n = len(phi)
+    AL, AR = _qp_gs(phi)
+    lBs, rBs = (qp_environments_finite(phi, H, lenvs, renvs) if phi.finite
+                else qp_environments_infinite(phi, H, lenvs, renvs, tol))
+    Xs = []
+    for loc in range(n):
+        B = phi.B(loc)
+        GL, GR = lenvs.leftenv(loc, phi.left_gs), renvs.rightenv(loc, phi.right_gs)
+        Bn = -energy[loc] * B + dAC(B, H[loc], GL, GR)
+        if loc > 0 or not phi.finite:
+            Bn = Bn + dAC(AR[loc], H[loc], lBs[loc], GR)
+        if loc < n - 1 or not phi.finite:
+            Bn = Bn + dAC(AL[loc], H[loc], GL, rBs[loc])
+        Xs.append(np.tensordot(np.conj(phi.VLs[loc]), Bn, axes=([0, 1], [0, 1])))    # setindex!  :101-104
+    return phi.with_Xs(Xs)
+
+
+def excitations_qp(H, phi0, lenvs, renvs=None, num=1, tol=1e-10, krylovdim=30, maxiter=100, env_tol=1e-12, dense=False):
+    """excitations(H, QuasiparticleAnsatz(), phi0, lenvs, renvs; num)  :39-53,127-143.  `dense` builds the matrix of
+    H_eff column by column and diagonalises it (small cases: also returns it, for the Hermiticity check)."""
+    renvs = lenvs if renvs is None else renvs
+    E = qp_renormalization_energy(H, phi0, lenvs, renvs)
+
+    def heff(v):
+        return effective_excitation_hamiltonian(H, phi0.from_vector(v), lenvs, renvs, E, env_tol).to_vector()
+    v0 = phi0.to_vector().astype(np.complex128)
+    if dense:
+        N = v0.size
+        M = np.stack([heff(np.eye(N, dtype=np.complex128)[k]) for k in range(N)], axis=1)
+        ev, S = np.linalg.eigh((M + M.conj().T) / 2)
+        return ev[:num], [phi0.from_vector(S[:, k]) for k in range(num)], M
+    Es, phis, found = [], [], []
+    for _ in range(num):                 # one Lanczos run per state; states already found are shifted up out of the way
+        def op(v):
+            w = heff(v)
+            for f, lf in zip(found, Es):
+                w = w + (10.0 + 10.0 * abs(lf)) * f * np.vdot(f, v)
+            return w
+        lam, v, _ = eigsolve_sr(op, v0, tol=tol, krylovdim=krylovdim, maxiter=maxiter)
+        found.append(v)
+        Es.append(lam)
+        phis.append(phi0.from_vector(v))
+    return np.array(Es), phis

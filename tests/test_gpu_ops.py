@@ -123,6 +123,19 @@ def test_transfer_plain_and_regularize(be, D, d):
         assert relerr(g, mo.regularize_env(e, lvec, rvec)) < 1e-12
 
 
+@pytest.mark.parametrize("D1,D2,W", [(70, 45, 2), (33, 64, 1), (1024, 1024, 1), (300, 1000, 3)])
+def test_regularize_rectangular_and_large(be, D1, D2, W):
+    """mpsk_regularize's tiled two-phase reduction: ragged tiles, rectangular slabs, several slabs, and the
+    1024 x 1024 case every GMRES step of the VUMPS / quasiparticle environments runs."""
+    rng = np.random.default_rng(D1 + D2)
+    env = [rng.standard_normal((D1, 1, D2)) for _ in range(W)]
+    lvec, rvec = rng.standard_normal((D2, D1)), rng.standard_normal((D1, D2))
+    dv = be.upload_env(env)
+    be.regularize(dv, be.upload(lvec), be.upload(rvec))
+    for g, e in zip(be.download_env(dv, [1] * W), env):
+        assert relerr(g, mo.regularize_env(e, lvec, rvec)) < 1e-12
+
+
 @pytest.mark.parametrize("M,N,K,tA,tB", [(64, 64, 64, 0, 0), (100, 37, 53, 0, 0), (100, 37, 53, 1, 0),
                                           (100, 37, 53, 0, 1), (100, 37, 53, 1, 1), (256, 128, 512, 1, 0),
                                           (128, 256, 64, 0, 1), (1, 1, 1, 0, 0), (130, 2, 1000, 1, 1)])

@@ -239,3 +239,54 @@ def test_finite_excited_states_match_ed(cb):
     ens_o, _ = mo.excitations_finite(Ho, mo.FiniteMPS.random(L, 2, 16, np.random.default_rng(0)) if False else
                                      mo.dmrg(mo.FiniteMPS.random(L, 2, 16, np.random.default_rng(0)), Ho, tol=1e-11, maxiter=30)[0], num=2)
     assert abs(ens[0] - ens_o[0]) < 1e-8 and abs(ens[1] - ens_o[1]) < 1e-8
+
+
+def _same_up_to_phase(a, b):
+    ov = np.vdot(a, b)
+    return np.abs(a * (ov / abs(ov)) - b).max()
+
+
+def test_quasiparticle_infinite_matches_oracle_and_exact_dispersion(cb):
+    """quasiparticleexcitation.jl:39-125 + qpenv.jl:55-144 on the product's host code (real / imaginary parts as separate
+    real tensors): on the SAME uniform ground state the excitation energies equal the oracle's complex-arithmetic ones,
+    the B tensors agree up to the eigenvector phase, and both reproduce the exact TFI dispersion
+    2 sqrt(J^2 + g^2 - 2 J g cos p) at momenta 0 (real path), 1.0 (two-part path) and pi (real path, negative phases)."""
+    J, g = 1.0, 2.0
+    Ho, Hg = mo.tfi_mpo(J, g), mk.transverse_field_ising(J, g, be=cb)
+    po, eo, _, _ = mo.vumps(mo.InfiniteMPS.random(2, 6, np.random.default_rng(1)), Ho, tol=1e-11, maxiter=100)
+    psi = mk.InfiniteMPS(*[[cb.upload(t) for t in lst] for lst in (po.AL, po.AR, po.CR, po.AC)], cb)
+    envs = mk.environments(psi, Hg)
+    for p in (0.0, 1.0, np.pi):
+        ens, phis = mk.excitations(Hg, mk.QuasiparticleAnsatz(), p, psi, envs, num=2 if p == 1.0 else 1)
+        exact = 2 * np.sqrt(J * J + g * g - 2 * J * g * np.cos(p))
+        ens_o, phis_o, M = mo.excitations_qp(Ho, mo.LeftGaugedQP.random(np.random.default_rng(0), po, momentum=p), eo, num=2, dense=True)
+        assert abs(ens[0] - ens_o[0]) < 1e-8 and abs(ens[0] - exact) < 1e-5, (p, ens, ens_o, exact)
+        assert phis[0].nparts == (2 if p == 1.0 else 1)
+        assert _same_up_to_phase(phis[0].B_host(0), phis_o[0].B(0)) < 1e-6
+        if p == 1.0:
+            assert abs(ens[1] - ens_o[1]) < 1e-7
+
+
+def test_quasiparticle_two_site_cell_and_finite(cb):
+    """(a) two-site unit cell (the `repeat(H, 2)` case of test/algorithms.jl:204-211): the same energy as the oracle and
+    as the exact dispersion folded into the halved Brillouin zone; (b) FiniteQP at full bond dimension: the tangent space is the
+    whole Hilbert space minus the ground state, so the quasiparticle energies are the exact gaps (dense ED)."""
+    J, g = 1.0, 1.7
+    Ho1, Hg1 = mo.tfi_mpo(J, g), mk.transverse_field_ising(J, g, be=cb)
+    Ho = mo.MPOHamiltonian([Ho1[0], Ho1[0]])
+    po, eo, _, _ = mo.vumps(mo.InfiniteMPS.random(2, 5, np.random.default_rng(2), n=2), Ho, tol=1e-11, maxiter=200)
+    H2 = mk.transverse_field_ising(J, g, be=cb)
+    H2.slices = [H2.slices[0], H2.slices[0]]
+    H2.period = 2
+    psi = mk.InfiniteMPS(*[[cb.upload(t) for t in lst] for lst in (po.AL, po.AR, po.CR, po.AC)], cb)
+    for p in (0.7, np.pi):
+        ens, _ = mk.excitations(H2, mk.QuasiparticleAnsatz(), p, psi, mk.environments(psi, H2))
+        ens_o, _ = mo.excitations_qp(Ho, mo.LeftGaugedQP.random(np.random.default_rng(0), po, momentum=p), eo)
+        assert abs(ens[0] - ens_o[0]) < 1e-8, (p, ens, ens_o)
+        eps = lambda k: 2 * np.sqrt(J * J + g * g - 2 * J * g * np.cos(k))          # noqa: E731
+        assert abs(ens[0] - min(eps(p), eps(p + np.pi))) < 1e-4                      # two-site cell: the band is folded
+    L = 6
+    ev = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho1, L))
+    p0, e0, _ = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 8, np.random.default_rng(0), be=cb), Hg1, mk.DMRG(tol=1e-12, maxiter=30))
+    ens, phis = mk.excitations(Hg1, mk.QuasiparticleAnsatz(), p0, e0, num=2)
+    assert abs(ens[0] - (ev[1] - ev[0])) < 1e-8 and abs(ens[1] - (ev[2] - ev[0])) < 1e-8, (ens, ev[:3] - ev[0])
