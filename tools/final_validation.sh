@@ -23,5 +23,6 @@ cd $R
 timeout -k 10 300 python tools/bench_site.py > $O/site_breakdown.log 2>&1
 timeout -k 10 600 python tools/bench_configs.py c2 c3 c4 tsvd c4sweep c4sweep:16:1024 ctdvp > $O/other_configs.log 2>&1
 for a in "4096 graded pre" "2048 graded pre" "1024 graded pre"; do timeout -k 10 120 python tools/svd_only.py $a 2>&1 | grep "^tsvd" >> $O/other_configs.log; done
+timeout -k 10 200 python tools/bench_qp.py 1024 > $O/bench_qp.log 2>&1
 MPSK_BENCH_PROF=1 timeout -k 10 300 python tools/bench_dac.py 1024,2,5 2048,2,5 1024,4,6 256,3,5 512,2,3 > $O/bench_dac.log 2>&1
 echo done
