@@ -181,4 +181,74 @@ function tsvd(theta::ROCTensor{2}; truncdim::Int=0, truncerr::Float64=0.0)
     return U, S, Vh, Int(kept[]), disc[]
 end
 
+# ---- MPO-less transfers + regularize!  (transfer.jl:18-45,66-75 ; transfermatrix.jl:70-76) ----
+# v is a slab tensor (W, D, D); W = 1 for the bond tensors of the uniform gauge / the identity levels of the
+# infinite environments.  The same two entry points take the excited tensor B of a quasiparticle state as the ket
+# (transfer.jl:48-62,113-126 with a trivial utility leg) and mixed (AR, AL) ket / bra pairs (qpenv.jl:66-97).
+function transfer_left(v::ROCTensor{3}, ::Nothing, A::ROCTensor{3}, Ab::ROCTensor{3})
+    W = v.dims[1]
+    out = ROCTensor((W, Ab.dims[3], A.dims[3]))
+    check(ccall((:mpsk_transfer_left, libmpsk[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        CTX[], C_NULL, W, A.dims[2], A.dims[1], A.dims[3], Ab.dims[1], Ab.dims[3], v.ptr, A.ptr, Ab.ptr, out.ptr))
+    return out
+end
+function transfer_right(v::ROCTensor{3}, ::Nothing, A::ROCTensor{3}, Ab::ROCTensor{3})
+    W = v.dims[1]
+    out = ROCTensor((W, A.dims[1], Ab.dims[1]))
+    check(ccall((:mpsk_transfer_right, libmpsk[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        CTX[], C_NULL, W, A.dims[2], A.dims[1], A.dims[3], Ab.dims[1], Ab.dims[3], A.ptr, Ab.ptr, v.ptr, out.ptr))
+    return out
+end
+"v[w] -= <lvec, v[w]> rvec on every slab (RegTransferMatrix, transfermatrix.jl:55,70-90)"
+function regularize!(v::ROCTensor{3}, lvec::ROCTensor{2}, rvec::ROCTensor{2})
+    check(ccall((:mpsk_regularize, libmpsk[]), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        CTX[], v.dims[1], v.dims[2], v.dims[3], v.ptr, lvec.ptr, rvec.ptr))
+    return v
+end
+
+# ---- small gauge products  AC = AL*C, C*AR, theta = AC*AR  (orthoview.jl:99,103 ; dmrg.jl:92) ----
+function mul(A::ROCTensor{2}, B::ROCTensor{2}; transA::Bool=false, transB::Bool=false, alpha=1.0)
+    M = transA ? A.dims[2] : A.dims[1]; K = transA ? A.dims[1] : A.dims[2]; N = transB ? B.dims[1] : B.dims[2]
+    Cm = ROCTensor((M, N))
+    check(ccall((:mpsk_gemm, libmpsk[]), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Float64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Int64),
+        CTX[], transA, transB, M, N, K, Float64(alpha), A.ptr, A.dims[1], B.ptr, B.dims[1], 0.0, Cm.ptr, M))
+    return Cm
+end
+
+# ---- the two-site split  al, c, ar = tsvd!(ac2; trunc) ; normalize!(c)   (dmrg.jl:96-104, tdvp.jl:124-126) ----
+# c comes back triangular instead of diagonal (al*c*ar is the same truncated theta, al / ar isometries): no rotation
+# accumulation in the Jacobi sweeps.  S holds the kept Schmidt values.
+function tsplit(theta::ROCTensor{2}; truncdim::Int=0, truncerr::Float64=0.0)
+    m, n = theta.dims; k = min(m, n); kmax = truncdim > 0 ? min(k, truncdim) : k
+    AL, Cm, AR, S = ROCTensor((m, kmax)), ROCTensor((kmax, kmax)), ROCTensor((kmax, n)), ROCTensor((kmax,))
+    kept = Ref{Cint}(0); disc = Ref{Float64}(0)
+    check(ccall((:mpsk_tsplit, libmpsk[]), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ref{Cint}, Ref{Float64}),
+        CTX[], m, n, theta.ptr, m, truncdim, truncerr, AL.ptr, m, Cm.ptr, kmax, AR.ptr, kmax, S.ptr, kept, disc))
+    return AL, Cm, AR, S, Int(kept[]), disc[]
+end
+
+# ---- two QRpos factorizations in flight (old and new AC of a right-moving site update: toolbox.jl:20 + orthoview.jl:56) ----
+function qrpos2(A1::ROCTensor{2}, A2::ROCTensor{2})
+    m, n = A1.dims
+    Q1, R1, Q2, R2 = ROCTensor((m, n)), ROCTensor((n, n)), ROCTensor((m, n)), ROCTensor((n, n))
+    check(ccall((:mpsk_qrpos2, libmpsk[]), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+        CTX[], m, n, A1.ptr, m, Q1.ptr, m, R1.ptr, n, A2.ptr, m, Q2.ptr, m, R2.ptr, n))
+    return (Q1, R1), (Q2, R2)
+end
+
+# ---- fused Krylov orthogonalisation step (KrylovKit ModifiedGramSchmidt2 replaced by CGS2 + normalise, ONE sync) ----
+function orth_step!(basis::Vector{<:ROCTensor}, y::ROCTensor)
+    k = length(basis)
+    ptrs = Ptr{Cvoid}[b.ptr for b in basis]
+    h = zeros(Float64, k); beta = Ref{Float64}(0)
+    check(ccall((:mpsk_vorth_step, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}),
+        CTX[], length(y), k, ptrs, y.ptr, h, beta))
+    return h, beta[]
+end
+
 end # module
