@@ -5,7 +5,8 @@ Import as ``import mpskit_jl_amd`` (the directory name contains a dot; the top-l
 """
 from ._lib import MpskError, LIB_PATH  # noqa: F401
 from .backend import Backend, DTensor, DeviceMPOSlice, default_backend  # noqa: F401
-from .operators import MPOHamiltonian, LazySum, heisenberg_XXX, transverse_field_ising, hubbard, from_twosite  # noqa: F401,E402
+from .operators import (MPOHamiltonian, LazySum, heisenberg_XXX, transverse_field_ising, hubbard, from_twosite,  # noqa: F401,E402
+                        periodic_boundary_conditions)
 from .states import FiniteMPS, InfiniteMPS  # noqa: F401,E402
 from .environments import FinEnv, MPOHamInfEnv, MultipleEnvironments, environments  # noqa: F401,E402
 from .derivatives import ddAC, ddAC2, ddC, MPO_ddAC, MPO_ddAC2, MPO_ddC  # noqa: F401,E402

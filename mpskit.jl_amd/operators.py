@@ -97,6 +97,100 @@ class MPOHamiltonian:
         return self._energy_slices[key]
 
 
+def _pbc_blocks(src, L, d):
+    """periodic_boundary_conditions(H::MPOHamiltonian, len)  (src/algorithms/toolbox.jl:186-307) as a state machine on
+    integer levels.  src[s] = (blocks {(j, k): scalar | [chi_j, d, d, chi_k]}, chil, chir) of the periodic slices.
+    New level (a, b, c): a = progress of the upper layer, b = the level 'lent' across the closing bond, c = progress of
+    the lower layer (the part of a wrapped term that sits at the beginning of the chain); b = odim-1 means nothing is lent
+    (the open-boundary terms).  Level dimension chi[a] * chi0[b] * chi[c], fused with a fastest.  A term never wraps twice.
+    Returns (data, nlev): data[site] = {(J, K): dense [chiJ, d, d, chiK]} for the L sites of the ring."""
+    p = len(src)
+    if L % p != 0:
+        raise ValueError(f"{L} is not a multiple of the unit cell")                       # :190-191
+    chi = len(src[0][1])
+    top = chi - 1
+    ind, n = {}, 0
+    for b in range(top, 0, -1):                                                           # :208-211
+        for c in range(b, chi):
+            ind[(0, b, c)] = n
+            n += 1
+    for a in range(1, chi):                                                               # :213-216
+        for b in range(top, a - 1, -1):
+            ind[(a, b, top)] = n
+            n += 1
+    chi0 = list(src[0][1])                               # dimensions of the lent leg: the bond that closes the ring
+    eye_d = np.eye(d)
+
+    def dense(O, cl, cr):
+        if np.isscalar(O):
+            return O * np.einsum("wv,ts->wtsv", np.eye(cl, cr), eye_d)
+        return np.asarray(O, dtype=float)
+
+    def upper(O, cb):          # O on the a leg, identity on the lent leg:  [(alpha, beta), t, s, (alpha', beta')]
+        ca, _, _, ca2 = O.shape
+        out = np.einsum("atsx,by->abtsxy", O, np.eye(cb))
+        return out.reshape(ca * cb, d, d, ca2 * cb, order="F")
+
+    def lower(O, cb):          # identity on the lent leg, O on the c leg:  [(beta, gamma), t, s, (beta', gamma')]
+        cc, _, _, cc2 = O.shape
+        out = np.einsum("by,gtsz->bgtsyz", np.eye(cb), O)
+        return out.reshape(cb * cc, d, d, cb * cc2, order="F")
+
+    data = []
+    for site in range(L):
+        blocks, chil, chir = src[site % p]
+        out = {}
+        for (j, k), O in blocks.items():
+            Od = dense(O, chil[j], chir[k])
+            if site == 0:                                                                 # starter  :258-281
+                if j == 0:
+                    out[(0, ind[(k, top, top)])] = Od
+                elif j < top:
+                    out[(0, ind[(0, j, k)])] = np.einsum("btsg->tsbg", Od).reshape(d, d, chil[j] * chir[k], order="F")[None]
+                continue
+            if site == L - 1:                                                             # ender  :283-296
+                if k >= 1:
+                    out[(ind[(j, k, top)], n - 1)] = np.einsum("atsb->abts", Od).reshape(chil[j] * chir[k], d, d, order="F")[..., None]
+                continue
+            for i in range(1, chi):                                                       # bulk, (j, k) above  :225-238
+                if k <= i:
+                    out[(ind[(j, i, top)], ind[(k, i, top)])] = upper(Od, chi0[i])
+            for l in range(1, top):                                                       # bulk, (j, k) below  :240-254
+                if l <= j:
+                    out[(ind[(0, l, j)], ind[(0, l, k)])] = lower(Od, chi0[l])
+        data.append(out)
+    return data, n
+
+
+def _pbc_level_dims(src, L, nlev):
+    """dimension of every new level on the L + 1 bonds of the ring MPO (see _pbc_blocks)."""
+    p, chi = len(src), len(src[0][1])
+    top = chi - 1
+    chi0 = list(src[0][1])
+    states = []
+    for b in range(top, 0, -1):
+        for c in range(b, chi):
+            states.append((0, b, c))
+    for a in range(1, chi):
+        for b in range(top, a - 1, -1):
+            states.append((a, b, top))
+    assert len(states) == nlev
+    dims = []
+    for s in range(L + 1):
+        cs = src[s % p][1] if s < L else src[(L - 1) % p][2]
+        dims.append([cs[a] * chi0[b] * cs[c] for (a, b, c) in states])
+    return dims
+
+
+def periodic_boundary_conditions(H: "MPOHamiltonian", L=None):
+    """periodic_boundary_conditions(H, len)  (toolbox.jl:181-307): the MPOHamiltonian of a ring of `len` sites, as an open
+    chain of `len` site-dependent slices with odim (odim - 1) levels."""
+    L = H.period if L is None else L
+    src = [(H[s].blocks, H[s].chil, H[s].chir) for s in range(H.period)]
+    data, nlev = _pbc_blocks(src, L, H.d)
+    return MPOHamiltonian(data, d=H.d, chis=_pbc_level_dims(src, L, nlev), be=H.be)
+
+
 # ---- models -----------------------------------------------------------------------------------
 
 def spin_ops(spin=0.5):

@@ -561,3 +561,24 @@ def test_quasiparticle_finite(be):
     ens, _ = mk.excitations(Hg, mk.QuasiparticleAnsatz(), p0, e0)
     ens_dm, _ = mk.excitations(Hg, mk.FiniteExcited(gsalg=mk.DMRG(tol=1e-8, maxiter=30)), p0)
     assert abs(ens_dm[0] - (ens[0] + E0)) < 1e-4, (ens_dm, ens, E0)
+
+
+def test_periodic_boundary_conditions_dmrg_equals_ed(be):
+    """test/algorithms.jl:512-540 through the HIP path: transverse_field_ising() on a ring of 10 sites
+    (periodic_boundary_conditions: 6-level site-dependent MPO with fused level dimensions up to 4, empty MPO columns at the
+    chain ends), FiniteMPS with D = 10 -> DMRG energy == exact diagonalization (1e-5 as in the reference); and the S = 1/2
+    Heisenberg ring of 12 sites (20 levels) at D = 64 against ED to 1e-8."""
+    mk = _mk()
+    L = 10
+    X, Z, E = np.array([[0., 1], [1, 0]]), np.diag([1., -1]), np.eye(2)
+    h2 = -(np.kron(Z, Z) + 0.5 * (np.kron(X, E) + np.kron(E, X))).reshape(2, 2, 2, 2)
+    Hp = mk.periodic_boundary_conditions(mk.from_twosite(h2, be=be), L)
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.periodic_boundary_conditions(mo.tfi_twosite_mpo(1.0), L), L))[0]
+    psi, envs, eps = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 10, np.random.default_rng(0), be=be), Hp, mk.DMRG(tol=1e-10, maxiter=30))
+    assert abs(float(np.sum(mk.expectation_value(psi, Hp, envs))) - e0) < 1e-5
+    L = 12
+    Hp = mk.periodic_boundary_conditions(mk.heisenberg_XXX(0.5, be=be), L)
+    assert Hp.odim == 20
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.periodic_boundary_conditions(mo.heisenberg_mpo(0.5), L), L))[0]
+    psi, envs, eps = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 64, np.random.default_rng(1), be=be), Hp, mk.DMRG(tol=1e-11, maxiter=40))
+    assert abs(float(np.sum(mk.expectation_value(psi, Hp, envs))) - e0) < 1e-8 * abs(e0)

@@ -290,3 +290,24 @@ def test_quasiparticle_two_site_cell_and_finite(cb):
     p0, e0, _ = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 8, np.random.default_rng(0), be=cb), Hg1, mk.DMRG(tol=1e-12, maxiter=30))
     ens, phis = mk.excitations(Hg1, mk.QuasiparticleAnsatz(), p0, e0, num=2)
     assert abs(ens[0] - (ev[1] - ev[0])) < 1e-8 and abs(ens[1] - (ev[2] - ev[0])) < 1e-8, (ens, ev[:3] - ev[0])
+
+
+def test_periodic_boundary_conditions_host(cb):
+    """periodic_boundary_conditions on the product's MPOHamiltonian: the same block table as the oracle's (dense operator
+    of the ring, chi > 1 middle level included) and the reference's known answer test/algorithms.jl:512-540 (ring of 10
+    sites, D = 10: DMRG energy == exact diagonalization) through the product's DMRG driver."""
+    L = 6
+    h2 = np.random.default_rng(0).standard_normal((2, 2, 2, 2))
+    h2 = h2 + np.transpose(h2, (2, 3, 0, 1))
+    Hp = mk.periodic_boundary_conditions(mk.from_twosite(h2, be=cb), L)
+    Ho = mo.periodic_boundary_conditions(mo.mpoham_from_twosite(h2), L)
+    assert Hp.odim == Ho.odim == 6 and Hp.period == L
+    as_oracle = mo.MPOHamiltonian([mo.SparseMPOSlice(Hp.odim, 2, Hp[s].chil, Hp[s].chir, Hp[s].blocks) for s in range(L)])
+    assert np.abs(mo.dense_hamiltonian(as_oracle, L) - mo.dense_hamiltonian(Ho, L)).max() < 1e-13
+    L = 10
+    X, Z, E = np.array([[0., 1], [1, 0]]), np.diag([1., -1]), np.eye(2)
+    h2 = -(np.kron(Z, Z) + 0.5 * (np.kron(X, E) + np.kron(E, X))).reshape(2, 2, 2, 2)
+    Hp = mk.periodic_boundary_conditions(mk.from_twosite(h2, be=cb), L)
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.periodic_boundary_conditions(mo.tfi_twosite_mpo(1.0), L), L))[0]
+    psi, envs, eps = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 10, np.random.default_rng(0), be=cb), Hp, mk.DMRG(tol=1e-10, maxiter=30))
+    assert abs(float(np.sum(mk.expectation_value(psi, Hp, envs))) - e0) < 1e-5
