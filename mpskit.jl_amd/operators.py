@@ -79,6 +79,53 @@ class MPOHamiltonian:
     def isid(self, i):  # mpohamiltonian.jl:53-58
         return all(s.isscal(i, i) and abs(s.blocks[(i, i)] - 1) < 1e-14 for s in self.slices)
 
+    # ---- arithmetic (mpohamiltonian.jl:77-160) ----
+    def _src(self):
+        return [(sl.blocks, sl.chil, sl.chir) for sl in self.slices]
+
+    def __mul__(self, other):
+        """b * a for two MPOHamiltonians (a applied first; sparsempo.jl:232-264) or b * number (mpohamiltonian.jl:147-154:
+        every block of the last column but the corner is scaled)."""
+        if isinstance(other, MPOHamiltonian):
+            if other.period != self.period:
+                raise ValueError(f"periodicity should match {self.period} != {other.period}")
+            data, dims = _mpo_product_data(other._src(), self._src(), self.d)
+            return MPOHamiltonian(data, d=self.d, chis=dims, be=self.be)
+        data = []
+        for sl in self.slices:
+            blk = dict(sl.blocks)
+            for (i, j), v in sl.blocks.items():
+                if j == self.odim - 1 and i < self.odim - 1:
+                    blk[(i, j)] = v * other
+            data.append(blk)
+        return MPOHamiltonian(data, d=self.d, chis=[list(c) for c in self.chis], be=self.be)
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self * -1.0
+
+    def __add__(self, e):
+        """H + e (mpohamiltonian.jl:78-94): e[c] * identity added to the on-site block (1, odim) of site c; H + H' is LazySum's job."""
+        e = np.broadcast_to(np.asarray(e, dtype=float), (self.period,))
+        data = []
+        for c, sl in enumerate(self.slices):
+            blk = dict(sl.blocks)
+            cur = blk.get((0, self.odim - 1), 0.0)
+            cur = cur * np.eye(self.d) if np.isscalar(cur) else np.asarray(cur)[0, :, :, 0]
+            blk[(0, self.odim - 1)] = (cur + e[c] * np.eye(self.d))[None, :, :, None]
+            data.append(blk)
+        return MPOHamiltonian(data, d=self.d, chis=[list(c) for c in self.chis], be=self.be)
+
+    def __sub__(self, e):
+        return self + (-np.asarray(e, dtype=float))
+
+    def repeat(self, n):
+        """Base.repeat(H, n)  (mpohamiltonian.jl:157)."""
+        data = [dict(sl.blocks) for sl in self.slices] * n
+        chis = [list(c) for c in self.chis[:-1]] * n + [list(self.chis[-1])]
+        return MPOHamiltonian(data, d=self.d, chis=chis, be=self.be)
+
     def energy_slice(self, site):
         """Slice holding only the blocks that enter the per-site energy of expval.jl:92-109
         ((j == 1 and k != 1) or (k == odim and j != odim)), halved unless (j, k) == (1, odim);
@@ -95,6 +142,33 @@ class MPOHamiltonian:
                 blocks[(j, k)] = f * v if np.isscalar(v) else f * np.asarray(v)
             self._energy_slices[key] = self.be.mposlice(odim, self.d, s.chil, s.chir, blocks)
         return self._energy_slices[key]
+
+
+def _mpo_product_data(srcA, srcB, d):
+    """SparseMPO product b * a (src/operators/sparsempo/sparsempo.jl:232-264): a is applied first.  srcX[s] = (blocks, chil,
+    chir).  New level (i, k) -> i + odim_a * k with dimension chi_a[i] * chi_b[k] (a's index fastest)."""
+    oa, ob = len(srcA[0][1]), len(srcB[0][1])
+    eye_d = np.eye(d)
+
+    def dense(O, cl, cr):
+        if np.isscalar(O):
+            return O * np.einsum("wv,ts->wtsv", np.eye(cl, cr), eye_d)
+        return np.asarray(O, dtype=float)
+    data, dims = [], []
+    for (ba, cla, cra), (bb, clb, crb) in zip(srcA, srcB):
+        out = {}
+        for (i, j), Oa in ba.items():
+            for (k, l), Ob in bb.items():
+                if np.isscalar(Oa) and np.isscalar(Ob):
+                    out[(i + oa * k, j + oa * l)] = Oa * Ob
+                    continue
+                A, B = dense(Oa, cla[i], cra[j]), dense(Ob, clb[k], crb[l])
+                t = np.einsum("ausx,btuy->abtsxy", A, B)                                   # :256-259
+                out[(i + oa * k, j + oa * l)] = t.reshape(A.shape[0] * B.shape[0], d, d, A.shape[3] * B.shape[3], order="F")
+        data.append(out)
+        dims.append([cla[i] * clb[k] for k in range(ob) for i in range(oa)])
+    dims.append([srcA[-1][2][i] * srcB[-1][2][k] for k in range(ob) for i in range(oa)])
+    return data, dims
 
 
 def _pbc_blocks(src, L, d):

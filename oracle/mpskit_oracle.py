@@ -1970,3 +1970,92 @@ def periodic_boundary_conditions(H: MPOHamiltonian, L=None):
     data, nlev = _pbc_blocks(src, L, H.d)
     dims = _pbc_level_dims(src, L, nlev)
     return MPOHamiltonian([SparseMPOSlice(nlev, H.d, dims[s], dims[s + 1], data[s]) for s in range(L)])
+
+
+# --------------------------------------------------------------------------------------
+# MPOHamiltonian arithmetic and the energy variance (src/operators/mpohamiltonian.jl:77-160,
+# sparsempo.jl:232-264, src/algorithms/toolbox.jl:128-172)
+# --------------------------------------------------------------------------------------
+def _mpo_product_data(srcA, srcB, d):
+    """SparseMPO product b * a (src/operators/sparsempo/sparsempo.jl:232-264): a is applied first.  srcX[s] = (blocks, chil,
+    chir).  New level (i, k) -> i + odim_a * k with dimension chi_a[i] * chi_b[k] (a's index fastest)."""
+    oa, ob = len(srcA[0][1]), len(srcB[0][1])
+    eye_d = np.eye(d)
+
+    def dense(O, cl, cr):
+        if np.isscalar(O):
+            return O * np.einsum("wv,ts->wtsv", np.eye(cl, cr), eye_d)
+        return np.asarray(O, dtype=float)
+    data, dims = [], []
+    for (ba, cla, cra), (bb, clb, crb) in zip(srcA, srcB):
+        out = {}
+        for (i, j), Oa in ba.items():
+            for (k, l), Ob in bb.items():
+                if np.isscalar(Oa) and np.isscalar(Ob):
+                    out[(i + oa * k, j + oa * l)] = Oa * Ob
+                    continue
+                A, B = dense(Oa, cla[i], cra[j]), dense(Ob, clb[k], crb[l])
+                t = np.einsum("ausx,btuy->abtsxy", A, B)                                   # :256-259
+                out[(i + oa * k, j + oa * l)] = t.reshape(A.shape[0] * B.shape[0], d, d, A.shape[3] * B.shape[3], order="F")
+        data.append(out)
+        dims.append([cla[i] * clb[k] for k in range(ob) for i in range(oa)])
+    dims.append([srcA[-1][2][i] * srcB[-1][2][k] for k in range(ob) for i in range(oa)])
+    return data, dims
+
+
+def mpoham_mul(b: MPOHamiltonian, a: MPOHamiltonian):
+    """b * a  (mpohamiltonian.jl:156)."""
+    srcA = [(a[s].Os, a[s].chil, a[s].chir) for s in range(a.period)]
+    srcB = [(b[s].Os, b[s].chil, b[s].chir) for s in range(b.period)]
+    data, dims = _mpo_product_data(srcA, srcB, a.d)
+    n = a.odim * b.odim
+    return MPOHamiltonian([SparseMPOSlice(n, a.d, dims[s], dims[s + 1], data[s]) for s in range(a.period)])
+
+
+def mpoham_shift(a: MPOHamiltonian, e):
+    """a + e  (mpohamiltonian.jl:78-94): e[c] * identity added to the on-site block (1, odim) of site c."""
+    e = np.broadcast_to(np.asarray(e, dtype=float), (a.period,))
+    out = []
+    for c in range(a.period):
+        blocks = dict(a[c].Os)
+        cur = blocks.get((0, a.odim - 1), 0.0)
+        cur = cur * np.eye(a.d) if np.isscalar(cur) else np.asarray(cur)[0, :, :, 0]
+        blocks[(0, a.odim - 1)] = (cur + e[c] * np.eye(a.d))[None, :, :, None]
+        out.append(SparseMPOSlice(a.odim, a.d, a[c].chil, a[c].chir, blocks))
+    return MPOHamiltonian(out)
+
+
+def variance_finite(psi, H, envs=None):
+    """variance(state::FiniteMPS, H)  toolbox.jl:140-144 :  <H*H> - <H>^2."""
+    envs = FinEnv(psi, H) if envs is None else envs
+    H2 = mpoham_mul(H, H)
+    return float(np.real(np.sum(expectation_value(psi, H2, FinEnv(psi, H2))) - np.sum(expectation_value(psi, H, envs)) ** 2))
+
+
+def variance_infinite(psi, H, envs=None, tol=1e-12):
+    """variance(state::InfiniteMPS, H)  toolbox.jl:135-138 : energy density of (H - e)^2."""
+    envs = MPOHamInfEnv(psi, H, tol=tol) if envs is None else envs
+    Hr = mpoham_shift(H, -np.real(expectation_value_inf(psi, H, envs)))
+    H2 = mpoham_mul(Hr, Hr)
+    return float(np.real(np.sum(expectation_value_inf(psi, H2, MPOHamInfEnv(psi, H2, tol=tol)))))
+
+
+def variance_qp_finite(phi, H, lenvs=None):
+    """variance(state::FiniteQP, H)  toolbox.jl:153-155.  The reference converts the quasiparticle state to a FiniteMPS
+    of twice the bond dimension; the same number from the tangent-space machinery: with H' = H - E0 / L,
+    <phi|H'^2|phi> = <X|H_eff[H'*H'] X> + <gs|H'^2|gs> and <phi|H'|phi> = <X|H_eff[H'] X>  (<X|X> = 1)."""
+    gs = phi.left_gs
+    lenvs = FinEnv(gs, H) if lenvs is None else lenvs
+    L = len(gs)
+    E0 = float(np.real(np.sum(expectation_value(gs, H, lenvs))))
+    Hr = mpoham_shift(H, -E0 / L)
+    H2 = mpoham_mul(Hr, Hr)
+    x = phi.to_vector()
+    x = x / np.linalg.norm(x)
+    out = []
+    for Hx in (Hr, H2):
+        e = FinEnv(gs, Hx)
+        en = qp_renormalization_energy(Hx, phi, e, e)
+        y = effective_excitation_hamiltonian(Hx, phi.from_vector(x), e, e, en).to_vector()
+        out.append(np.vdot(x, y) + en[0])
+    return float(np.real(out[1] - out[0] ** 2))

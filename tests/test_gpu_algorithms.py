@@ -582,3 +582,30 @@ def test_periodic_boundary_conditions_dmrg_equals_ed(be):
     e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.periodic_boundary_conditions(mo.heisenberg_mpo(0.5), L), L))[0]
     psi, envs, eps = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 64, np.random.default_rng(1), be=be), Hp, mk.DMRG(tol=1e-11, maxiter=40))
     assert abs(float(np.sum(mk.expectation_value(psi, Hp, envs))) - e0) < 1e-8 * abs(e0)
+
+
+def test_variance_and_mpo_product(be):
+    """variance(state, H) (toolbox.jl:128-155) through the HIP path: <H * H> runs the environment / matvec kernels with
+    W = odim^2 = 25 MPO levels (fused level dimensions for the SVD-split two-site operator).  Random finite / uniform states
+    against the oracle; converged ground states as in test/algorithms.jl:14-94 (`variance < 1e-2` there; far tighter
+    here); the finite quasiparticle state of test/algorithms.jl:235 (`variance(phi, H) < 1e-6`)."""
+    mk = _mk()
+    rng = np.random.default_rng(0)
+    L = 7
+    h2 = rng.standard_normal((2, 2, 2, 2))
+    h2 = h2 + np.transpose(h2, (2, 3, 0, 1))
+    psi = mo.FiniteMPS.random(L, 2, 5, rng)
+    pg = mk.FiniteMPS([psi.AC(i) if i == L - 1 else psi.AL(i) for i in range(L)], be=be)
+    for Hg, Ho in ((mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)), (mk.from_twosite(h2, be=be), mo.mpoham_from_twosite(h2))):
+        assert abs(mk.variance(pg, Hg) - mo.variance_finite(psi, Ho)) < 1e-11
+    Hi, Hio = mk.transverse_field_ising(1.0, 2.0, be=be), mo.tfi_mpo(1.0, 2.0)
+    pr = mo.InfiniteMPS.random(2, 4, rng)
+    pgi = mk.InfiniteMPS(*[[be.upload(t) for t in lst] for lst in (pr.AL, pr.AR, pr.CR, pr.AC)], be)
+    assert abs(mk.variance(pgi, Hi) - mo.variance_infinite(pr, Hio)) < 1e-10
+    p, e, eps = mk.find_groundstate(mk.InfiniteMPS.random(2, 12, np.random.default_rng(2), be=be), Hi, mk.VUMPS(tol=1e-11, maxiter=100))
+    assert abs(mk.variance(p, Hi, e)) < 1e-8
+    Ht = mk.transverse_field_ising(1.0, 1.5, be=be)
+    p0, e0, _ = mk.find_groundstate(mk.FiniteMPS.random(20, 2, 15, np.random.default_rng(1), be=be), Ht, mk.DMRG(tol=1e-10, maxiter=30))
+    assert abs(mk.variance(p0, Ht, e0)) < 1e-8
+    ens, phis = mk.excitations(Ht, mk.QuasiparticleAnsatz(), p0, e0)
+    assert mk.variance(phis[0], Ht, e0) < 1e-6

@@ -311,3 +311,33 @@ def test_periodic_boundary_conditions_host(cb):
     e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.periodic_boundary_conditions(mo.tfi_twosite_mpo(1.0), L), L))[0]
     psi, envs, eps = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 10, np.random.default_rng(0), be=cb), Hp, mk.DMRG(tol=1e-10, maxiter=30))
     assert abs(float(np.sum(mk.expectation_value(psi, Hp, envs))) - e0) < 1e-5
+
+
+def test_mpo_arithmetic_and_variance_host(cb):
+    """MPOHamiltonian.__mul__ / __add__ / scalar * / repeat and toolbox.variance on the product's host code: same numbers as
+    the oracle (random finite state incl. fused chi > 1 levels, random uniform state, truncated finite quasiparticle)."""
+    rng = np.random.default_rng(0)
+    L = 7
+    h2 = rng.standard_normal((2, 2, 2, 2))
+    h2 = h2 + np.transpose(h2, (2, 3, 0, 1))
+    psi = mo.FiniteMPS.random(L, 2, 5, rng)
+    pg = mk.FiniteMPS([psi.AC(i) if i == L - 1 else psi.AL(i) for i in range(L)], be=cb)
+    for Hg, Ho in ((mk.heisenberg_XXX(0.5, be=cb), mo.heisenberg_mpo(0.5)), (mk.from_twosite(h2, be=cb), mo.mpoham_from_twosite(h2))):
+        assert abs(mk.variance(pg, Hg) - mo.variance_finite(psi, Ho)) < 1e-11
+        e1 = float(np.sum(mk.expectation_value(pg, Hg, mk.environments(pg, Hg))))
+        H3 = 2.0 * Hg + 0.25
+        assert abs(float(np.sum(mk.expectation_value(pg, H3, mk.environments(pg, H3)))) - (2 * e1 + 0.25 * L)) < 1e-11
+    Hi, Hio = mk.transverse_field_ising(1.0, 2.0, be=cb), mo.tfi_mpo(1.0, 2.0)
+    pr = mo.InfiniteMPS.random(2, 4, rng)
+    pgi = mk.InfiniteMPS(*[[cb.upload(t) for t in lst] for lst in (pr.AL, pr.AR, pr.CR, pr.AC)], cb)
+    assert abs(mk.variance(pgi, Hi) - mo.variance_infinite(pr, Hio)) < 1e-10
+    assert Hi.repeat(2).period == 2
+    Ht, Hto, L = mk.transverse_field_ising(1.0, 1.5, be=cb), mo.tfi_mpo(1.0, 1.5), 9
+    p0, e0, _ = mk.find_groundstate(mk.FiniteMPS.random(L, 2, 4, np.random.default_rng(1), be=cb), Ht, mk.DMRG(tol=1e-10, maxiter=30))
+    ens, phis = mk.excitations(Ht, mk.QuasiparticleAnsatz(), p0, e0)
+    var = mk.variance(phis[0], Ht, e0)
+    assert 1e-7 < var < 1e-2
+    po = mo.FiniteMPS([cb.download(p0.AC(i)) if i == L - 1 else cb.download(p0.AL(i)) for i in range(L)])
+    eo = mo.FinEnv(po, Hto)
+    _, phis_o = mo.excitations_qp(Hto, mo.LeftGaugedQP.random(np.random.default_rng(0), po, dtype=np.float64), eo)
+    assert abs(var - mo.variance_qp_finite(phis_o[0], Hto, eo)) < 1e-9

@@ -338,3 +338,45 @@ def test_periodic_dmrg_equals_exact_diagonalization():
     e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Hp, L))[0]
     psi, envs, _, log = mo.dmrg(mo.FiniteMPS.random(L, 2, 10, np.random.default_rng(0)), Hp, tol=1e-10, maxiter=30)
     assert abs(log[-1][1] - e0) < 1e-5
+
+
+def _qp_dense_vector(phi):
+    """|phi> = sum_i AL .. AL B_i AR .. AR as a dense vector (finite quasiparticle state)."""
+    L = len(phi)
+    gs = phi.left_gs
+    tot = 0
+    for i in range(L):
+        v = np.ones((1, 1))
+        for s in range(L):
+            A = gs.AL(s) if s < i else (phi.B(s) if s == i else gs.AR(s))
+            v = np.tensordot(v, A, axes=([v.ndim - 1], [0])).reshape(-1, A.shape[2])
+        tot = tot + v.reshape(-1)
+    return tot
+
+
+def test_mpo_product_shift_and_variance():
+    """mpohamiltonian.jl:78-94,156 + sparsempo.jl:232-264 + toolbox.jl:135-155 : the dense operator of H * H is the square of
+    the dense H (chi = 1 and fused chi > 1 levels), H + e shifts the spectrum by L e, and `variance` equals <H^2> - <H>^2 of
+    the dense vectors for a random FiniteMPS and for a truncated finite quasiparticle state (the tangent-space formula
+    against the explicit sum over positions); a converged uniform state has zero variance density."""
+    rng = np.random.default_rng(0)
+    L = 7
+    for H in (mo.heisenberg_mpo(0.5), mo.mpoham_from_twosite((lambda h: h + np.transpose(h, (2, 3, 0, 1)))(rng.standard_normal((2, 2, 2, 2))))):
+        Hd = mo.dense_hamiltonian(H, L)
+        assert np.abs(mo.dense_hamiltonian(mo.mpoham_mul(H, H), L) - Hd @ Hd).max() < 1e-12
+        assert np.abs(mo.dense_hamiltonian(mo.mpoham_shift(H, 0.3), L) - Hd - 0.3 * L * np.eye(Hd.shape[0])).max() < 1e-12
+        psi = mo.FiniteMPS.random(L, 2, 5, rng)
+        v = mo.mps_to_vector(psi)
+        v = v / np.linalg.norm(v)
+        assert abs(mo.variance_finite(psi, H) - (v @ Hd @ Hd @ v - (v @ Hd @ v) ** 2)) < 1e-12
+    Ht, L = mo.tfi_mpo(1.0, 1.5), 9
+    Hd = mo.dense_hamiltonian(Ht, L)
+    p0, e0, *_ = mo.dmrg(mo.FiniteMPS.random(L, 2, 4, rng), Ht, tol=1e-10, maxiter=30)
+    _, phis = mo.excitations_qp(Ht, mo.LeftGaugedQP.random(rng, p0, dtype=np.float64), e0)
+    w = _qp_dense_vector(phis[0])
+    w = w / np.linalg.norm(w)
+    exact = w @ Hd @ Hd @ w - (w @ Hd @ w) ** 2
+    assert exact > 1e-7 and abs(mo.variance_qp_finite(phis[0], Ht, e0) - exact) < 1e-10
+    Hi = mo.tfi_mpo(1.0, 2.0)
+    pi_, _, eps, _ = mo.vumps(mo.InfiniteMPS.random(2, 6, rng), Hi, tol=1e-11, maxiter=100)
+    assert eps < 1e-9 and abs(mo.variance_infinite(pi_, Hi)) < 1e-8
