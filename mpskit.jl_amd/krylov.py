@@ -285,3 +285,33 @@ def gmres(be: Backend, matvec, b: DTensor, x0: DTensor, tol=1e-12, krylovdim=30,
         if res <= tol:
             break
     return x
+
+
+def arnoldi_eigvals(be: Backend, matvec, x0: DTensor, num=1, tol=1e-10, krylovdim=60, ws: KrylovWorkspace | None = None):
+    """The `num` largest-magnitude eigenvalues (complex in general) of a real non-symmetric operator matvec(x, out): one
+    Arnoldi factorisation of dimension <= krylovdim, Ritz values of the Hessenberg matrix on the host; a Ritz value counts
+    as converged when |beta * s_last| < tol (KrylovKit eigsolve(..., :LM) stand-in for `transfer_spectrum`, toolbox.jl:44-58).
+    Returns (eigenvalues sorted by decreasing magnitude, number converged)."""
+    ws = KrylovWorkspace(be) if ws is None else ws
+    shape = x0.shape
+    krylovdim = int(min(krylovdim, x0.size))
+    V = ws.get(shape, krylovdim + 1)
+    be.axpby(1.0 / be.norm(x0), x0, 0.0, V[0])
+    Hm = np.zeros((krylovdim + 1, krylovdim))
+    k = 0
+    vals, conv = np.zeros(0, dtype=complex), 0
+    while k < krylovdim:
+        matvec(V[k], V[k + 1])
+        h, beta = be.orth_step(V[:k + 1], V[k + 1])
+        Hm[:k + 1, k] = h
+        Hm[k + 1, k] = beta
+        k += 1
+        if k >= num and (k % 5 == 0 or k == krylovdim or beta < 1e-300):
+            ev, S = np.linalg.eig(Hm[:k, :k])
+            order = np.argsort(-np.abs(ev))
+            vals = ev[order]
+            res = np.abs(beta * S[-1, order])
+            conv = int(np.sum(res[:num] < tol))
+            if conv >= min(num, k) or beta < 1e-300:
+                break
+    return vals[:num], conv

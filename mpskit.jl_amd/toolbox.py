@@ -37,3 +37,77 @@ def variance(state, H, envs=None):
     Hr = H - expectation_value(state, H, envs)                                    # :135-138
     H2 = Hr * Hr
     return float(np.sum(expectation_value(state, H2, environments(state, H2))))
+
+
+def _xlogx_trace(be, c):
+    """-tr(rho log rho) with rho = c c^dag from the singular values of c (mpsk_tsvd)."""
+    _, S, _, kept, _ = be.tsvd(c)
+    s2 = np.asarray(be.download(S)).reshape(-1)[:kept] ** 2
+    s2 = s2[s2 > 0]
+    return float(-np.sum(s2 * np.log(s2)))
+
+
+def entanglement_spectrum(state, site=0):
+    """entanglement_spectrum(psi; site)  (toolbox.jl:60-75): singular values of the bond matrix CR[site]."""
+    c = state.CR(site) if isinstance(state, FiniteMPS) else state.CR[site % len(state)]
+    _, S, _, kept, _ = state.be.tsvd(c)
+    return np.asarray(state.be.download(S)).reshape(-1)[:kept]
+
+
+def entropy(state, loc=None):
+    """entropy(state[, loc])  (toolbox.jl:1-5): -tr(rho log rho) of the bond right of site loc; all bonds of the unit cell for
+    an InfiniteMPS without loc."""
+    be = state.be
+    if loc is None:
+        if isinstance(state, FiniteMPS):
+            raise TypeError("entropy(state::FiniteMPS) needs a site")
+        return [_xlogx_trace(be, c) for c in state.CR]
+    return _xlogx_trace(be, state.CR(loc) if isinstance(state, FiniteMPS) else state.CR[loc % len(state)])
+
+
+def transfer_spectrum(above, below=None, tol=1e-10, num_vals=20, krylovdim=None, rng=None):
+    """transfer_spectrum(above; below, num_vals)  (toolbox.jl:44-58): leading eigenvalues of v -> v * T(above.AL, below.AL)
+    through the unit cell (mpsk_transfer_left without an MPO); complex in general."""
+    from . import krylov
+    below = above if below is None else below
+    be = above.be
+    n = len(above)
+    Da, Db = above.AL[0].shape[0], below.AL[0].shape[0]
+    rng = np.random.default_rng(0) if rng is None else rng
+    x0 = be.upload(rng.standard_normal((1, Db, Da))).reshape(1, Db, Da)
+    num_vals = min(num_vals, Da * Db)
+
+    def op(x, out):
+        y = x
+        for s in range(n):
+            y = be.transfer_left(None, y, above.AL[s], below.AL[s])
+        be.axpby(1.0, y, 0.0, out)
+        return out
+    kd = max(3 * num_vals + 10, 40) if krylovdim is None else krylovdim
+    vals, conv = krylov.arnoldi_eigvals(be, op, x0, num=num_vals, tol=tol, krylovdim=kd)
+    if conv < num_vals:
+        import warnings
+        warnings.warn(f"correlation length failed to converge: {conv} of {num_vals} values")     # :54-55
+    return vals
+
+
+def marek_gap(spectrum, tol_angle=0.1):
+    """marek_gap(spectrum)  (toolbox.jl:77-113): inverse correlation length eps, the gap delta between the two leading
+    values at the dominant angle, and that angle."""
+    spectrum = np.asarray(spectrum, dtype=complex)
+    spectrum = spectrum[np.abs(spectrum) < 1 - 1e-12]
+    order = np.argsort(-np.abs(spectrum))
+    spectrum = spectrum[order]
+    angles = np.angle(spectrum)
+    angles = np.where(angles < -1e-12, angles + 2 * np.pi, angles)
+    theta = angles[0]
+    at = spectrum[np.abs(angles - theta) < tol_angle]
+    lambdas = -np.log(np.abs(at))
+    delta = lambdas[1] - lambdas[0] if len(lambdas) > 2 else np.inf
+    return float(lambdas[0]), float(delta), float(theta)
+
+
+def correlation_length(above, **kw):
+    """correlation_length(psi::InfiniteMPS)  (toolbox.jl:115-125)."""
+    eps, _, _ = marek_gap(transfer_spectrum(above, **kw))
+    return 1.0 / eps

@@ -192,6 +192,17 @@ class CpuBackend:
         l, q = mo.lqpos(self.download(A))
         return self.upload(l), self.upload(q)
 
+    def tsvd(self, theta, max_keep=0, trunc_err=0.0):
+        """mpsk_tsvd: full thin factors + the number kept under truncdim / truncerr and the discarded 2-norm."""
+        self._count("tsvd")
+        a = self.download(theta)
+        U, S, Vh = np.linalg.svd(a, full_matrices=False)
+        k = len(S) if not max_keep else min(len(S), int(max_keep))
+        if trunc_err > 0:
+            while k > 1 and np.sqrt(np.sum(S[k - 1:] ** 2)) <= trunc_err:
+                k -= 1
+        return self.upload(U), self.upload(S), self.upload(Vh), k, float(np.sqrt(np.sum(S[k:] ** 2)))
+
     def qr_stats(self):
         return dict(self._qr)
 

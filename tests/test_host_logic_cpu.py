@@ -341,3 +341,21 @@ def test_mpo_arithmetic_and_variance_host(cb):
     eo = mo.FinEnv(po, Hto)
     _, phis_o = mo.excitations_qp(Hto, mo.LeftGaugedQP.random(np.random.default_rng(0), po, dtype=np.float64), eo)
     assert abs(var - mo.variance_qp_finite(phis_o[0], Hto, eo)) < 1e-9
+
+
+def test_transfer_spectrum_and_correlation_length_host(cb):
+    """transfer_spectrum / marek_gap / correlation_length (toolbox.jl:44-125) on the host Arnoldi: the leading eigenvalues of the
+    mixed transfer matrix equal those of the dense D^2 x D^2 matrix built from AL."""
+    from mpskit_jl_amd import toolbox
+    rng = np.random.default_rng(5)
+    po = mo.InfiniteMPS.random(2, 5, rng, n=2)
+    psi = mk.InfiniteMPS(*[[cb.upload(t) for t in lst] for lst in (po.AL, po.AR, po.CR, po.AC)], cb)
+    T = np.eye(25)
+    for a in po.AL:
+        T = T @ np.einsum("asb,psq->paqb", a, a.conj()).reshape(25, 25)
+    ref = np.linalg.eigvals(T)
+    ref = ref[np.argsort(-np.abs(ref))]
+    vals = toolbox.transfer_spectrum(psi, num_vals=4, krylovdim=25)
+    assert abs(vals[0] - 1) < 1e-10
+    assert np.abs(np.sort(np.abs(vals)) - np.sort(np.abs(ref[:4]))).max() < 1e-8
+    assert abs(toolbox.correlation_length(psi, num_vals=4, krylovdim=25) + 1 / np.log(np.abs(ref[1]))) < 1e-6
