@@ -15,4 +15,5 @@ from .algorithms import (DMRG, DMRG2, VUMPS, IDMRG1, IDMRG2, TDVP, TDVP2, Arnold
 from .changebonds import changebonds, OptimalExpand, SvdCut  # noqa: F401,E402
 from .excitations import excitations, FiniteExcited, ProjectionOperator  # noqa: F401,E402
 from .quasiparticle import QuasiparticleAnsatz, LeftGaugedQP  # noqa: F401,E402
-from .toolbox import variance, entropy, entanglement_spectrum, transfer_spectrum, marek_gap, correlation_length  # noqa: F401,E402
+from .toolbox import (variance, entropy, entanglement_spectrum, transfer_spectrum, marek_gap, correlation_length,  # noqa: F401,E402
+                      exact_diagonalization)

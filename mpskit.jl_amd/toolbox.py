@@ -111,3 +111,46 @@ def correlation_length(above, **kw):
     """correlation_length(psi::InfiniteMPS)  (toolbox.jl:115-125)."""
     eps, _, _ = marek_gap(transfer_spectrum(above, **kw))
     return 1.0 / eps
+
+
+def exact_diagonalization(H, len=None, num=1, tol=1e-12, krylovdim=30, maxiter=100, rng=None):
+    """exact_diagonalization(H; len, num, which = :SR)  (src/algorithms/ED.jl:4-53): the largest possible FiniteMPS of that
+    length (identity isometries left and right of the middle site), so that the effective Hamiltonian of the middle site IS
+    the full Hamiltonian; its lowest eigenpairs by the Krylov solver over mpsk_dAC.  Returns (energies, states)."""
+    from . import krylov
+    from .derivatives import ddAC
+    L = H.period if len is None else int(len)
+    be, d = H.be, H.d
+    rng = np.random.default_rng(0) if rng is None else rng
+    # ED.jl:13 takes middle_site = round(len / 2); any site works (no truncation anywhere).  Here the balanced one, so that
+    # every tensor of the state is a tall (Dl d >= Dr) / wide (Dl <= d Dr) matrix the QRpos / LQpos kernels accept.
+    mid = (L - 1) // 2
+    As, left = [], 1
+    for _ in range(mid):                                                          # :23-27
+        As.append(np.eye(left * d).reshape(left, d, left * d, order="F"))
+        left *= d
+    rights, right = [], 1
+    for _ in range(L - 1, mid, -1):                                               # :28-33
+        rights.append(np.eye(right * d).reshape(right * d, d, right, order="F"))
+        right *= d
+    As.append(rng.standard_normal((left, d, right)))                              # :34-37
+    As.extend(reversed(rights))
+    state = FiniteMPS(As, normalize=True, be=be)
+    envs = environments(state, H)
+    H_ac = ddAC(mid, state, H, envs)                                              # "this linear operator is now the actual full hamiltonian"
+    found, vals, states = [], [], []
+    ws = krylov.KrylovWorkspace(be)
+    for _ in range(num):
+        def op(x, out):
+            H_ac(x, out=out)
+            for f, lf in zip(found, vals):                                        # states already found are shifted up out of the way
+                be.axpby((10.0 + 10.0 * abs(lf)) * be.dot(f, x), f, 1.0, out)
+            return out
+        lam, v, _, res = krylov.eigsolve_sr(be, op, state.AC(mid), tol=tol, krylovdim=krylovdim, maxiter=maxiter, ws=ws)
+        v = be.copy(v)
+        found.append(v)
+        vals.append(float(lam))
+        cs = state.copy()
+        cs.set_AC(mid, be.copy(v))
+        states.append(cs)
+    return vals, states

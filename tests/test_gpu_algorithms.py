@@ -639,3 +639,22 @@ def test_entropy_spectrum_and_correlation_length(be):
     p, e, eps = mk.find_groundstate(mk.InfiniteMPS.random(2, 16, np.random.default_rng(2), be=be), H, mk.VUMPS(tol=1e-11, maxiter=100))
     xi = toolbox.correlation_length(p, num_vals=6)
     assert abs(xi - 1 / np.log(g / J)) < 5e-2 * xi, xi        # D = 16: 1.415 vs 1.4427 (finite-entanglement effect)
+
+
+def test_exact_diagonalization(be):
+    """exact_diagonalization (ED.jl:4-53) on the HIP path: the middle-site effective Hamiltonian of the full-bond-dimension
+    FiniteMPS is the whole Hamiltonian -- lowest levels of an L = 12 Heisenberg chain (mpsk_dAC on a 64 x 2 x 32 tensor) and of an
+    L = 9 TFI chain against dense ED; the ring of test/algorithms.jl:538 (`exact_diagonalization(th)` of the periodic TFI)."""
+    mk = _mk()
+    from mpskit_jl_amd import toolbox
+    for L, Hg, Ho in ((12, mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)), (9, mk.transverse_field_ising(1.0, 0.8, be=be), mo.tfi_mpo(1.0, 0.8))):
+        ev = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))
+        vals, states = toolbox.exact_diagonalization(Hg, len=L, num=2)
+        assert abs(vals[0] - ev[0]) < 1e-10 * abs(ev[0])
+        assert min(abs(vals[1] - e) for e in ev[1:4]) < 1e-8
+        assert abs(float(np.sum(mk.expectation_value(states[0], Hg, mk.environments(states[0], Hg)))) - ev[0]) < 1e-10 * abs(ev[0])
+    L = 10
+    Hp = mk.periodic_boundary_conditions(mk.transverse_field_ising(1.0, 1.0, be=be), L)
+    e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.periodic_boundary_conditions(mo.tfi_mpo(1.0, 1.0), L), L))[0]
+    vals, _ = toolbox.exact_diagonalization(Hp)
+    assert abs(vals[0] - e0) < 1e-10 * abs(e0)

@@ -359,3 +359,15 @@ def test_transfer_spectrum_and_correlation_length_host(cb):
     assert abs(vals[0] - 1) < 1e-10
     assert np.abs(np.sort(np.abs(vals)) - np.sort(np.abs(ref[:4]))).max() < 1e-8
     assert abs(toolbox.correlation_length(psi, num_vals=4, krylovdim=25) + 1 / np.log(np.abs(ref[1]))) < 1e-6
+
+
+def test_exact_diagonalization_host(cb):
+    """exact_diagonalization (ED.jl:4-53): full-bond-dimension FiniteMPS + the middle-site effective Hamiltonian == dense ED,
+    for an even and an odd length, the three lowest levels; the returned states carry the energies."""
+    from mpskit_jl_amd import toolbox
+    for L, Hg, Ho in ((6, mk.heisenberg_XXX(0.5, be=cb), mo.heisenberg_mpo(0.5)), (5, mk.transverse_field_ising(1.0, 0.8, be=cb), mo.tfi_mpo(1.0, 0.8))):
+        ev = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))
+        vals, states = toolbox.exact_diagonalization(Hg, len=L, num=2)
+        assert abs(vals[0] - ev[0]) < 1e-10
+        assert min(abs(vals[1] - e) for e in ev[1:4]) < 1e-9
+        assert abs(float(np.sum(mk.expectation_value(states[0], Hg, mk.environments(states[0], Hg)))) - ev[0]) < 1e-10
