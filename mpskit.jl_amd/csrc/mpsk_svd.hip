@@ -493,11 +493,85 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   auto drop_events = [&]() { for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(evW[b]); (void)hipEventDestroy(evV[b]); } };
   long rc = 0;                              // global round counter
   int vcur = 0;
+  // V-free mode (mpsk_tsplit): nothing runs on s2, and the rotation kernel (latency-bound, one workgroup per pair) leaves
+  // most of the chip idle for ~100 us per round.  The round-robin order has LOCAL dependencies -- pair p of round r+1 is
+  // made of columns that sat in pairs p-1 / p+1 (or p itself at the two ends) in round r -- so the pairs are cut into NG
+  // contiguous groups, each on its own stream: a group starts round r+1 as soon as ITS neighbours have finished the
+  // update of round r (events, two sets by round parity), no barrier across all pairs.  Groups drift out of phase and
+  // the rotations of one group run under the Gram / update GEMMs of the others.  Ping-pong buffer hazards are covered
+  // by the same events (a group writes only slots of its own and its neighbours' pairs).
+  // MEASURED AND REJECTED as the default (MI355X, 4096^2 split, same 14 sweeps, identical results): 416 ms with one
+  // stream, 477 ms with 2 groups, 672 ms with 4 -- the cross-queue event waits (2 per group and round) and the 4x
+  // launch count cost more than the overlap returns.  Kept behind MPSK_SVD_GROUPS=2..4 for future runtimes.
+  int NG = 1;
+  hipStream_t gst[4] = {s, s, s, s};
+  hipEvent_t evU[2][4], evS = nullptr;
+  if (vfree && P >= 16) {
+    if (const char* ev = getenv("MPSK_SVD_GROUPS")) { NG = atoi(ev); if (NG < 1) NG = 1; if (NG > 4) NG = 4; }
+  }
+  if (NG > 1) {
+    static hipStream_t extra[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < NG - 1; ++i) {
+      if (!extra[i] && hipStreamCreateWithFlags(&extra[i], hipStreamNonBlocking) != hipSuccess) { NG = 1; break; }
+      gst[i + 1] = extra[i];
+    }
+  }
+  if (NG > 1) {
+    for (int b = 0; b < 2; ++b)
+      for (int g2 = 0; g2 < NG; ++g2)
+        if ((e = hipEventCreateWithFlags(&evU[b][g2], hipEventDisableTiming)) != hipSuccess) { drop_events(); return e; }
+    if ((e = hipEventCreateWithFlags(&evS, hipEventDisableTiming)) != hipSuccess) { drop_events(); return e; }
+  }
+  auto drop_group_events = [&]() {
+    if (NG > 1) {
+      for (int b = 0; b < 2; ++b) for (int g2 = 0; g2 < NG; ++g2) (void)hipEventDestroy(evU[b][g2]);
+      (void)hipEventDestroy(evS);
+    }
+  };
+  auto sync_groups = [&]() -> hipError_t {
+    for (int g2 = NG - 1; g2 >= 1; --g2) { hipError_t e2 = hipStreamSynchronize(gst[g2]); if (e2 != hipSuccess) return e2; }
+    return hipSuccess;
+  };
   for (int sweep = 0; sweep < 40; ++sweep) {
-    if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) { drop_events(); return e; }
+    if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+    if (NG > 1) {
+      (void)hipEventRecord(evS, s);
+      for (int g2 = 1; g2 < NG; ++g2) (void)hipStreamWaitEvent(gst[g2], evS, 0);
+    }
     for (int r = 0; r < rounds; ++r, ++rc) {
       const int wb = (int)(rc & 1);
       double* Wb = Wm + (size_t)wb * P * J2 * J2;
+      if (NG > 1) {
+        const int eb = (int)(rc & 1), pb = eb ^ 1;
+        for (int g2 = 0; g2 < NG; ++g2) {
+          hipStream_t sg = gst[g2];
+          const int p0 = (int)((int64_t)P * g2 / NG), pn = (int)((int64_t)P * (g2 + 1) / NG) - p0;
+          if (rc > 0) {                       // neighbours' updates of the previous round
+            if (g2 > 0) (void)hipStreamWaitEvent(sg, evU[pb][g2 - 1], 0);
+            if (g2 < NG - 1) (void)hipStreamWaitEvent(sg, evU[pb][g2 + 1], 0);
+          }
+          GemmArgs g;
+          std::memset(&g, 0, sizeof(g));
+          g.A = G[cur]; g.B = G[cur]; g.C = Mpart; g.M = J2; g.N = J2; g.lda = mm; g.ldb = mm; g.ldc = J2;
+          g.batch = pn * Q; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = 1; g.transB = 0;
+          g.tabA = t_gramA + (size_t)p0 * Q; g.tabB = g.tabA; g.tabC = t_gramC + (size_t)p0 * Q; g.tabs_even = kq_even;
+          g.K = kq;
+          if ((e = gemm_f64(g, sg)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+          hipLaunchKernelGGL(jacobi_eig_kernel, dim3(pn), dim3(256), 0, sg, Mpart + (size_t)p0 * Q * J2 * J2, Q,
+                             Wb + (size_t)p0 * J2 * J2, tol, flag, inner_sweeps);
+          GemmArgs u;
+          std::memset(&u, 0, sizeof(u));
+          u.B = Wb; u.N = J2; u.K = J2; u.ldb = J2; u.batch = pn; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
+          u.tabB = t_updB + p0; u.tabs_even = kq_even; u.splitN = JB;
+          u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G + p0; u.tabC = t_updC_G + p0;
+          u.tabC2 = t_updC_G + P + p0;
+          if ((e = gemm_f64(u, sg)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+          (void)hipEventRecord(evU[eb][g2], sg);
+        }
+        cur ^= 1;
+        vcur ^= 1;
+        continue;
+      }
       // 1. Gram (TN): M[p][q] = X_p[rows of split q]^T X_p[rows of split q]
       GemmArgs g;
       std::memset(&g, 0, sizeof(g));
@@ -529,8 +603,9 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       vcur ^= 1;
     }
     ++sweeps;
-    if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) { drop_events(); return e; }
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) { drop_events(); return e; }
+    if ((e = sync_groups()) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+    if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
     double mx;
     std::memcpy(&mx, &hflag, sizeof(double));
     if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] sweep %d: max |cos| = %.3e (tol %.1e)\n", sweeps, mx, tol);
@@ -543,6 +618,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     if ((e = hipStreamSynchronize(s2)) != hipSuccess) { drop_events(); return e; }
   }
   drop_events();
+  drop_group_events();
   if (sweeps_out) *sweeps_out = sweeps;
   if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] %d x %d: P=%d Q=%d rounds/sweep=%d sweeps=%d\n", mm, nn, P, Q, rounds, sweeps);
 
