@@ -375,6 +375,7 @@ static SvdPlan svd_plan(int m, int n) {
   int target = 1024 / p.P;           // aim at ~1024 Gram tiles per round (and k-tiles too short for split-K)
   if (target < 1) target = 1;
   if (target > 16) target = 16;
+  if (const char* ev = getenv("MPSK_SVD_Q")) { int t = atoi(ev); if (t >= 1 && t <= 16) target = t; }
   int q = 1;                         // largest divisor of mm <= target with >= 128 (even) rows per split
   for (int c = target; c >= 2; --c)
     if (p.mm % c == 0 && (p.mm / c) % 2 == 0 && p.mm / c >= 128) { q = c; break; }
