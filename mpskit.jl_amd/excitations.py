@@ -116,7 +116,9 @@ def excitations(H, alg, *args, **kw):
         if getattr(psi, "cplx", False):
             raise NotImplementedError("QuasiparticleAnsatz on complex (embedded) ground states")
         rng = kw.pop("rng", None)
-        return excitations_qp(H, alg, LeftGaugedQP.random(psi, 0.0, rng), *rest, **kw)
+        rpsi = rest[1] if len(rest) > 1 else None            # (lmps, lenvs, rmps, renvs) as in the reference
+        rest = rest[:1] + rest[2:]
+        return excitations_qp(H, alg, LeftGaugedQP.random(psi, 0.0, rng, rpsi), *rest, **kw)
     if getattr(args[1], "cplx", False):
         raise NotImplementedError("QuasiparticleAnsatz on complex (embedded) ground states")
     return excitations_momenta(H, alg, *args, **kw)

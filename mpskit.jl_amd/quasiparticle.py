@@ -18,9 +18,10 @@ parts with one mpsk_vlincomb each.  That is 2x the real flops for a general mome
 under a real operator (no bond embedding, no complex GEMM).  The Hermitian eigenproblem on C^N becomes the symmetric one on
 R^{2N} = [Re | Im] with every eigenvalue doubled (v and i v); the Lanczos solver sees an ordinary real vector.
 
-Built: LeftGaugedQP with left_gs is right_gs (topologically trivial), FiniteQP and InfiniteQP over an MPOHamiltonian.  Not
-built: domain walls between two different ground states, charged sectors, the statistical-mechanics (MPOMultiline) variant,
-RightGaugedQP conversion, `variance` of a QP state."""
+Built: LeftGaugedQP over an MPOHamiltonian -- FiniteQP, InfiniteQP at any momentum, topologically trivial
+(left_gs is right_gs, regularised environments) and domain-wall excitations between two different ground states (no
+regularisation, energies renormalised by the mean of the two); `variance` of a finite QP state (toolbox.py).  Not built:
+charged sectors, the statistical-mechanics (MPOMultiline) variant, RightGaugedQP conversion."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -51,8 +52,9 @@ class LeftGaugedQP:
     """quasiparticle_state.jl:8-17 : B[i] = VL[i] X[i],  AL[i]^dag VL[i] = 0.  `vec` is the flat device vector
     [Re X_0 .. Re X_{n-1} | Im X_0 .. Im X_{n-1}] (the second half only for a complex momentum phase)."""
 
-    def __init__(self, gs, VLs, xshapes, momentum, vec: DTensor, nparts):
-        self.left_gs = self.right_gs = gs
+    def __init__(self, gs, VLs, xshapes, momentum, vec: DTensor, nparts, right_gs=None):
+        self.left_gs = gs
+        self.right_gs = gs if right_gs is None else right_gs       # !(left_gs === right_gs) => domain-wall excitation  :9-11
         self.be = gs.be
         self.VLs, self.xshapes, self.momentum, self.vec, self.nparts = VLs, xshapes, momentum, vec, nparts
         self.finite = isinstance(gs, FiniteMPS)
@@ -60,16 +62,17 @@ class LeftGaugedQP:
         self.N = int(self.offs[-1])
 
     @classmethod
-    def random(cls, gs, momentum=0.0, rng=None):
-        """LeftGaugedQP(rand, left_gs; momentum)  :33-46 ; VL from a projected random block + QRpos (any orthonormal
-        basis of the complement of AL spans the same tangent space)."""
+    def random(cls, gs, momentum=0.0, rng=None, right_gs=None):
+        """LeftGaugedQP(rand, left_gs, right_gs; momentum)  :33-46 ; VL from a projected random block + QRpos (any
+        orthonormal basis of the complement of AL spans the same tangent space)."""
         from .changebonds import _complement_cols
         be = gs.be
         rng = np.random.default_rng(0) if rng is None else rng
         finite = isinstance(gs, FiniteMPS)
         n = len(gs)
         ALs = [gs.AL(i) for i in range(n)] if finite else gs.AL
-        ARs = [gs.AR(i) for i in range(n)] if finite else gs.AR
+        rgs = gs if right_gs is None else right_gs
+        ARs = [rgs.AR(i) for i in range(n)] if finite else rgs.AR
         VLs, shapes = [], []
         for i in range(n):
             Dl, d, Dr = ALs[i].shape
@@ -78,17 +81,17 @@ class LeftGaugedQP:
         nparts = 1 if (finite or abs(np.sin(momentum)) < 1e-12) else 2
         N = sum(a * b for a, b in shapes)
         vec = be.upload(rng.random(N * nparts))
-        return cls(gs, VLs, shapes, 0.0 if finite else float(momentum), vec, nparts)
+        return cls(gs, VLs, shapes, 0.0 if finite else float(momentum), vec, nparts, right_gs)
 
     @property
     def trivial(self):
-        return True
+        return self.left_gs is self.right_gs
 
     def __len__(self):
         return len(self.VLs)
 
     def with_vec(self, vec):
-        return LeftGaugedQP(self.left_gs, self.VLs, self.xshapes, self.momentum, vec, self.nparts)
+        return LeftGaugedQP(self.left_gs, self.VLs, self.xshapes, self.momentum, vec, self.nparts, self.right_gs)
 
     def X(self, part, i, vec=None):
         vec = self.vec if vec is None else vec
@@ -139,24 +142,30 @@ def _phase(be, z, ang):
 class _QPContext:
     """Everything that does not depend on X: ground-state tensors, environments, regularisation bonds, energies."""
 
-    def __init__(self, H, phi: LeftGaugedQP, lenvs, alg: QuasiparticleAnsatz):
+    def __init__(self, H, phi: LeftGaugedQP, lenvs, alg: QuasiparticleAnsatz, renvs=None):
         self.H, self.alg, self.be = H, alg, phi.be
         be = self.be
-        gs = phi.left_gs
+        gs, rgs = phi.left_gs, phi.right_gs
+        self.trivial = phi.trivial
+        renvs = lenvs if (renvs is None and self.trivial) else (_environments(rgs, H) if renvs is None else renvs)
         n = self.n = len(phi)
         self.finite = phi.finite
         self.p = phi.momentum
         self.AL = [gs.AL(i) for i in range(n)] if self.finite else list(gs.AL)
-        self.AR = [gs.AR(i) for i in range(n)] if self.finite else list(gs.AR)
-        AC = [gs.AC(i) for i in range(n)] if self.finite else list(gs.AC)
+        self.AR = [rgs.AR(i) for i in range(n)] if self.finite else list(rgs.AR)
         self.GL = [lenvs.leftenv(i, gs) for i in range(n)]
-        self.GR = [lenvs.rightenv(i, gs) for i in range(n)]
-        # effective_excitation_renormalization_energy  :330-362 (trivial: left energies only)
-        self.E = [be.dot(AC[i], be.dAC(H[i], self.GL[i], self.GR[i], AC[i])) for i in range(n)]
+        self.GR = [renvs.rightenv(i, rgs) for i in range(n)]
+
+        def energies(st, envs):        # effective_excitation_renormalization_energy  :330-362
+            AC = [st.AC(i) for i in range(n)] if self.finite else list(st.AC)
+            return [be.dot(AC[i], be.dAC(H[i], envs.leftenv(i, st), envs.rightenv(i, st), AC[i])) for i in range(n)]
+        self.E = energies(gs, lenvs)
+        if not self.trivial:
+            self.E = [(a + b) / 2 for a, b in zip(self.E, energies(rgs, renvs))]
         self.odim = H.odim
         self.ids = [i for i in range(1, self.odim - 1) if H.isid(i)]
         self.ws = krylov.KrylovWorkspace(be)
-        if not self.finite:
+        if not self.finite and self.trivial:
             self.C = list(gs.CR)                                                    # bond right of site s
             self.Ct = [be.upload(np.ascontiguousarray(be.download(c).T)) for c in self.C]
 
@@ -174,6 +183,8 @@ class _QPContext:
         return self.be.regularize(v, self.Ct[bond % self.n], self.C[bond % self.n])
 
     def _reg_ids(self, z, chis, bond):
+        if not self.trivial:                # qpenv.jl:68,85 `if exci.trivial`
+            return z
         for part in z:
             lv = self._levels(part, chis)
             for i in self.ids:
@@ -224,7 +235,7 @@ class _QPContext:
             start = v[i]
             if start is not None:
                 start = _phase(be, start, ang)
-                if H.isid(i):
+                if H.isid(i) and self.trivial:
                     for part in start:
                         self._reg(part, n - 1)
             b = _acc(be, [be.copy(x) for x in start_levels[i]], start)
@@ -244,7 +255,7 @@ class _QPContext:
                         for st in sites:
                             O = 1.0 if isid else H[st].blocks[(i, i)]
                             y = self._tblock(left, y, O, ket[st], bra[st])
-                        if isid:
+                        if isid and self.trivial:
                             self._reg(y, n - 1)
                         ys.append(y)
                     if nparts == 1:
@@ -350,11 +361,11 @@ def _times_i_vec(be, phi, v):
     return out
 
 
-def excitations_qp(H, alg: QuasiparticleAnsatz, phi0: LeftGaugedQP, lenvs=None, num=1):
-    """excitations(H, alg, phi0::QP, lenvs; num)  :39-53,127-143 -> (energies, [LeftGaugedQP])."""
+def excitations_qp(H, alg: QuasiparticleAnsatz, phi0: LeftGaugedQP, lenvs=None, renvs=None, num=1):
+    """excitations(H, alg, phi0::QP, lenvs, renvs; num)  :39-64,127-143 -> (energies, [LeftGaugedQP])."""
     be = phi0.be
     lenvs = _environments(phi0.left_gs, H) if lenvs is None else lenvs
-    ctx = _QPContext(H, phi0, lenvs, alg)
+    ctx = _QPContext(H, phi0, lenvs, alg, renvs)
     eig_ws = krylov.KrylovWorkspace(be)      # NOT ctx.ws: the GMRES solves run inside this solver's matvec
     found, Es = [], []
     for _ in range(num):
@@ -378,16 +389,19 @@ def excitations_qp(H, alg: QuasiparticleAnsatz, phi0: LeftGaugedQP, lenvs=None, 
     return [Es[k] for k in keep], [phi0.with_vec(found[k]) for k in keep]
 
 
-def excitations_momenta(H, alg: QuasiparticleAnsatz, momenta, psi, lenvs=None, num=1, rng=None):
-    """excitations(H, alg, momentum | momenta, psi::InfiniteMPS, envs; num)  :84-125.  A scalar momentum returns
-    (energies[num], states[num]); a list returns (E[len(momenta), num], states[len(momenta)][num])."""
+def excitations_momenta(H, alg: QuasiparticleAnsatz, momenta, psi, lenvs=None, rpsi=None, renvs=None, num=1, rng=None):
+    """excitations(H, alg, momentum | momenta, lmps::InfiniteMPS, lenvs, rmps, renvs; num)  :84-125.  A scalar momentum
+    returns (energies[num], states[num]); a list returns (E[len(momenta), num], states[len(momenta)][num]).  rmps different
+    from lmps: domain-wall (topologically non-trivial) excitations between two ground states."""
     lenvs = _environments(psi, H) if lenvs is None else lenvs
+    rpsi = psi if rpsi is None else rpsi
+    renvs = (lenvs if rpsi is psi else _environments(rpsi, H)) if renvs is None else renvs
     rng = np.random.default_rng(0) if rng is None else rng
     if np.isscalar(momenta):
-        return excitations_qp(H, alg, LeftGaugedQP.random(psi, momenta, rng), lenvs, num)
+        return excitations_qp(H, alg, LeftGaugedQP.random(psi, momenta, rng, rpsi), lenvs, renvs, num)
     Ep, Bp = [], []
     for p in momenta:
-        e, b = excitations_qp(H, alg, LeftGaugedQP.random(psi, float(p), rng), lenvs, num)
+        e, b = excitations_qp(H, alg, LeftGaugedQP.random(psi, float(p), rng, rpsi), lenvs, renvs, num)
         Ep.append(e)
         Bp.append(b)
     return np.array(Ep), Bp

@@ -13,8 +13,8 @@ from .states import FiniteMPS
 def variance(state, H, envs=None):
     from .quasiparticle import LeftGaugedQP, QuasiparticleAnsatz, _QPContext
     if isinstance(state, LeftGaugedQP):
-        if not state.finite:
-            raise NotImplementedError("variance of an infinite quasiparticle state")
+        if not state.finite or not state.trivial:
+            raise NotImplementedError("variance of an infinite / domain-wall quasiparticle state")
         # toolbox.jl:153-155 converts the state to a FiniteMPS of twice the bond dimension; the same number from the
         # tangent-space machinery: with H' = H - E0 / L,  <phi|H'^2|phi> = <X|H_eff[H' * H'] X> + <gs|H'^2|gs>,
         # <phi|H'|phi> = <X|H_eff[H'] X>  for <X|X> = 1

@@ -658,3 +658,28 @@ def test_exact_diagonalization(be):
     e0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.periodic_boundary_conditions(mo.tfi_mpo(1.0, 1.0), L), L))[0]
     vals, _ = toolbox.exact_diagonalization(Hp)
     assert abs(vals[0] - e0) < 1e-10 * abs(e0)
+
+
+def test_quasiparticle_domain_wall(be):
+    """Domain-wall quasiparticles on the HIP path (left and right ground states differ: mixed (AR_right, AL_left) transfers
+    without regularisation, right environments of the second state): the kink between the two symmetry-broken TFI ground
+    states == the oracle == the exact dispersion 2 sqrt(1 + g^2 - 2 g cos p)."""
+    mk = _mk()
+    g = 0.5
+    Ho = mo.tfi_mpo(1.0, g)
+    po, eo, eps, _ = mo.vumps(mo.InfiniteMPS.random(2, 8, np.random.default_rng(4)), Ho, tol=1e-11, maxiter=200)
+    X = np.array([[0., 1], [1, 0]])
+    flip = lambda A: np.einsum("ts,asb->atb", X, A)     # noqa: E731
+    po2 = mo.InfiniteMPS([flip(a) for a in po.AL], [flip(a) for a in po.AR], [c.copy() for c in po.CR], [flip(a) for a in po.AC])
+    eo2 = mo.MPOHamInfEnv(po2, Ho)
+    up = lambda st: mk.InfiniteMPS(*[[be.upload(t) for t in lst] for lst in (st.AL, st.AR, st.CR, st.AC)], be)   # noqa: E731
+    pl, pr = up(po), up(po2)
+    Hg = mk.transverse_field_ising(1.0, g, be=be)
+    VLs = [mo.leftnull(a) for a in po.AL]
+    for p in (0.0, 0.8, np.pi):
+        ens, phis = mk.excitations(Hg, mk.QuasiparticleAnsatz(), p, pl, mk.environments(pl, Hg), pr, mk.environments(pr, Hg))
+        phi_o = mo.LeftGaugedQP(po, po2, VLs, [np.random.default_rng(0).random((VLs[0].shape[2], 8)) + 0j], momentum=p)
+        ens_o, _ = mo.excitations_qp(Ho, phi_o, eo, eo2)
+        exact = 2 * np.sqrt(1 + g * g - 2 * g * np.cos(p))
+        assert not phis[0].trivial
+        assert abs(ens[0] - ens_o[0]) < 1e-8 and abs(ens[0] - exact) < 1e-6, (p, ens, ens_o, exact)

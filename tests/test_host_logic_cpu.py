@@ -371,3 +371,32 @@ def test_exact_diagonalization_host(cb):
         assert abs(vals[0] - ev[0]) < 1e-10
         assert min(abs(vals[1] - e) for e in ev[1:4]) < 1e-9
         assert abs(float(np.sum(mk.expectation_value(states[0], Hg, mk.environments(states[0], Hg)))) - ev[0]) < 1e-10
+
+
+def _tfi_symmetry_broken_pair(be, g, D, seed):
+    """the two Z2-related ground states of the ferromagnetic TFI chain (oracle VUMPS + spin flip), as oracle and product states."""
+    Ho = mo.tfi_mpo(1.0, g)
+    po, eo, eps, _ = mo.vumps(mo.InfiniteMPS.random(2, D, np.random.default_rng(seed)), Ho, tol=1e-11, maxiter=200)
+    assert eps < 1e-8
+    X = np.array([[0., 1], [1, 0]])
+    flip = lambda A: np.einsum("ts,asb->atb", X, A)     # noqa: E731
+    po2 = mo.InfiniteMPS([flip(a) for a in po.AL], [flip(a) for a in po.AR], [c.copy() for c in po.CR], [flip(a) for a in po.AC])
+    up = lambda st: mk.InfiniteMPS(*[[be.upload(t) for t in lst] for lst in (st.AL, st.AR, st.CR, st.AC)], be)   # noqa: E731
+    return Ho, po, eo, po2, mo.MPOHamInfEnv(po2, Ho), up(po), up(po2)
+
+
+def test_quasiparticle_domain_wall_host(cb):
+    """Topologically non-trivial quasiparticles (quasiparticle_state.jl:9-11, qpenv.jl:68,85: no regularisation; energies
+    renormalised by the mean of the two ground states): the kink between the two symmetry-broken TFI ground states has the
+    exact dispersion 2 sqrt(1 + g^2 - 2 g cos p); product host code == oracle == exact."""
+    g = 0.5
+    Ho, po, eo, po2, eo2, pl, pr = _tfi_symmetry_broken_pair(cb, g, 8, 4)
+    Hg = mk.transverse_field_ising(1.0, g, be=cb)
+    for p in (0.0, 0.8):
+        ens, phis = mk.excitations(Hg, mk.QuasiparticleAnsatz(), p, pl, mk.environments(pl, Hg), pr, mk.environments(pr, Hg))
+        assert not phis[0].trivial
+        VLs = [mo.leftnull(a) for a in po.AL]
+        phi_o = mo.LeftGaugedQP(po, po2, VLs, [np.random.default_rng(0).random((VLs[0].shape[2], 8)) + 0j], momentum=p)
+        ens_o, _ = mo.excitations_qp(Ho, phi_o, eo, eo2)
+        exact = 2 * np.sqrt(1 + g * g - 2 * g * np.cos(p))
+        assert abs(ens[0] - ens_o[0]) < 1e-8 and abs(ens[0] - exact) < 1e-6, (p, ens, ens_o, exact)

@@ -380,3 +380,25 @@ def test_mpo_product_shift_and_variance():
     Hi = mo.tfi_mpo(1.0, 2.0)
     pi_, _, eps, _ = mo.vumps(mo.InfiniteMPS.random(2, 6, rng), Hi, tol=1e-11, maxiter=100)
     assert eps < 1e-9 and abs(mo.variance_infinite(pi_, Hi)) < 1e-8
+
+
+def test_quasiparticle_domain_wall_exact_kink_dispersion():
+    """Domain-wall quasiparticles (left_gs !== right_gs: quasiparticle_state.jl:9-11; qpenv.jl:68,85 skip the regularisation;
+    quasiparticleexcitation.jl:345-361 renormalise by the mean energy): between the two Z2-related ground states of the
+    ferromagnetic TFI chain the effective Hamiltonian is Hermitian and its lowest eigenvalue is the exact one-kink
+    dispersion 2 sqrt(1 + g^2 - 2 g cos p)."""
+    g = 0.5
+    H = mo.tfi_mpo(1.0, g)
+    psi, envs, eps, _ = mo.vumps(mo.InfiniteMPS.random(2, 8, np.random.default_rng(4)), H, tol=1e-11, maxiter=200)
+    assert eps < 1e-8
+    X = np.array([[0., 1], [1, 0]])
+    flip = lambda A: np.einsum("ts,asb->atb", X, A)     # noqa: E731
+    psi2 = mo.InfiniteMPS([flip(a) for a in psi.AL], [flip(a) for a in psi.AR], [c.copy() for c in psi.CR], [flip(a) for a in psi.AC])
+    envs2 = mo.MPOHamInfEnv(psi2, H)
+    VLs = [mo.leftnull(a) for a in psi.AL]
+    for p in (0.0, 0.8, np.pi):
+        phi = mo.LeftGaugedQP(psi, psi2, VLs, [np.random.default_rng(0).random((VLs[0].shape[2], 8)) + 0j], momentum=p)
+        assert not phi.trivial
+        ev, _, M = mo.excitations_qp(H, phi, envs, envs2, num=1, dense=True)
+        assert np.abs(M - M.conj().T).max() < 1e-10
+        assert abs(ev[0] - 2 * np.sqrt(1 + g * g - 2 * g * np.cos(p))) < 1e-6
