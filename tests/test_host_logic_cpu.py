@@ -400,3 +400,23 @@ def test_quasiparticle_domain_wall_host(cb):
         ens_o, _ = mo.excitations_qp(Ho, phi_o, eo, eo2)
         exact = 2 * np.sqrt(1 + g * g - 2 * g * np.cos(p))
         assert abs(ens[0] - ens_o[0]) < 1e-8 and abs(ens[0] - exact) < 1e-6, (p, ens, ens_o, exact)
+
+
+def test_quasiparticle_long_range_hamiltonian(cb):
+    """A Hamiltonian with a decaying (non-identity diagonal) MPO level: -sum Z Z - g sum X + sum_{r>=1} c lam^(r-1) X_i X_{i+r}.
+    The quasiparticle transfer systems then solve (1 - e^{-+ip} lam T) on that level (exci_transfer_system.jl:29-31,72-74);
+    the oracle's effective Hamiltonian stays Hermitian and the product host code gives the same energies."""
+    X, Z = np.array([[0., 1], [1, 0]]), np.diag([1., -1])
+    g, c, lam = 2.0, 0.3, 0.5
+    blocks = {(0, 0): 1.0, (3, 3): 1.0, (0, 1): -Z, (1, 3): Z, (0, 2): c * X, (2, 2): lam, (2, 3): X, (0, 3): -g * X}
+    Ho = mo.MPOHamiltonian([mo.mpoham_from_chain(blocks, 2)])
+    Hg = mk.MPOHamiltonian(blocks, be=cb)
+    po, eo, eps, _ = mo.vumps(mo.InfiniteMPS.random(2, 6, np.random.default_rng(3)), Ho, tol=1e-11, maxiter=200)
+    assert eps < 1e-8
+    psi = mk.InfiniteMPS(*[[cb.upload(t) for t in lst] for lst in (po.AL, po.AR, po.CR, po.AC)], cb)
+    envs = mk.environments(psi, Hg)
+    for p in (0.0, 1.3):
+        ev, _, M = mo.excitations_qp(Ho, mo.LeftGaugedQP.random(np.random.default_rng(0), po, momentum=p), eo, num=1, dense=True)
+        assert np.abs(M - M.conj().T).max() < 1e-9
+        ens, _ = mk.excitations(Hg, mk.QuasiparticleAnsatz(), p, psi, envs)
+        assert abs(ens[0] - ev[0]) < 1e-8, (p, ens, ev)
