@@ -576,9 +576,13 @@ class IDMRG2:  # idmrg.jl:89-96 ; trscheme = truncerr(1e-6)
     eig_tol_factor: float = 1e-5
 
 
-def _host_inv(be, C: DTensor):
-    """inv(C) of a bond matrix (D x D, tiny next to the contractions): on the host, like the reference's dense inv."""
-    return be.upload(np.linalg.inv(be.download(C)))
+def _bond_inv(be, C: DTensor):
+    """inv(C) of a bond matrix (idmrg.jl:118,150 `inv(psi.CR[..])`) on the device: C = U S Vh by mpsk_tsvd,
+    inv(C) = Vh^T diag(1/S) U^T by two GEMMs (only the D reciprocals pass through the host)."""
+    U, S, Vh, k, _ = be.tsvd(C)
+    sv = np.asarray(be.download(S)).reshape(-1)
+    W = be.gemm(Vh, be.upload(np.diag(1.0 / sv)), transA=True)
+    return be.gemm(W, U, transB=True)
 
 
 def _idmrg2(ost, H, alg: IDMRG2, oenvs=None):  # idmrg.jl:97-204
@@ -612,13 +616,13 @@ def _idmrg2(ost, H, alg: IDMRG2, oenvs=None):  # idmrg.jl:97-204
             envs.update_leftenv(psi, pos + 1)
             envs.update_rightenv(psi, pos)
         # edge (sites n-1, 0):  AC[end] inv(CR[end]) . AL[1] CR[1]
-        left = mul_AC(be, psi.AC[n - 1], _host_inv(be, psi.CR[n - 1]))
+        left = mul_AC(be, psi.AC[n - 1], _bond_inv(be, psi.CR[n - 1]))
         right = mul_AC(be, psi.AL[0], psi.CR[0])
         al, c, ar = solve(_two_site_tensor(be, left, right), n - 1, 0, eig)
         psi.AC[n - 1] = mul_AC(be, al, c)
         psi.AL[n - 1], psi.CR[n - 1], psi.AR[0] = al, c, ar
         psi.AC[0] = mul_CA(be, c, ar)
-        psi.AL[0] = mul_AC(be, psi.AC[0], _host_inv(be, psi.CR[0]))
+        psi.AL[0] = mul_AC(be, psi.AC[0], _bond_inv(be, psi.CR[0]))
         c_cur = c
         envs.update_leftenv(psi, 0)
         envs.update_rightenv(psi, n - 1)
@@ -631,9 +635,9 @@ def _idmrg2(ost, H, alg: IDMRG2, oenvs=None):  # idmrg.jl:97-204
             envs.update_rightenv(psi, pos)
         # edge again:  CR[end-1] AR[end] . inv(CR[end]) AC[1]
         left = mul_CA(be, psi.CR[n - 2], psi.AR[n - 1])
-        right = mul_CA(be, _host_inv(be, psi.CR[n - 1]), psi.AC[0])
+        right = mul_CA(be, _bond_inv(be, psi.CR[n - 1]), psi.AC[0])
         al, c, ar = solve(_two_site_tensor(be, left, right), n - 1, 0, eig)
-        psi.AR[n - 1] = mul_CA(be, _host_inv(be, psi.CR[n - 2]), mul_AC(be, al, c))
+        psi.AR[n - 1] = mul_CA(be, _bond_inv(be, psi.CR[n - 2]), mul_AC(be, al, c))
         psi.AL[n - 1], psi.CR[n - 1], psi.AR[0] = al, c, ar
         psi.AC[0] = mul_CA(be, c, ar)
         envs.update_leftenv(psi, 0)
