@@ -445,3 +445,15 @@ def test_tsplit(be, m, n, k):
     assert np.abs(al @ c @ ar - best).max() < 1e-12
     assert np.abs(np.linalg.svd(c, compute_uv=False) - s[:kk]).max() < 1e-13
     assert np.abs(np.tril(c, -1)).max() < 1e-13 or np.abs(np.triu(c, 1)).max() < 1e-13
+
+
+def test_bond_matrix_inverse_on_device(be):
+    """inv(CR) of the IDMRG2 edge step (idmrg.jl:118,150) by mpsk_tsvd + two GEMMs, graded spectrum included."""
+    from mpskit_jl_amd import algorithms as alg
+    rng = np.random.default_rng(3)
+    for D, grade in ((12, 0.0), (96, 0.0), (64, 6.0)):
+        U, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        V, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        Cm = (U * np.logspace(0, -grade, D)) @ V.T if grade else rng.standard_normal((D, D))
+        inv = be.download(alg._bond_inv(be, be.upload(Cm)))
+        assert np.abs(inv @ Cm - np.eye(D)).max() < 1e-9 * np.linalg.cond(Cm)
