@@ -167,7 +167,7 @@ class _QPContext:
         self.ws = krylov.KrylovWorkspace(be)
         if not self.finite and self.trivial:
             self.C = list(gs.CR)                                                    # bond right of site s
-            self.Ct = [be.upload(np.ascontiguousarray(be.download(c).T)) for c in self.C]
+            self.Ct = [be.gemm(c, be.upload(np.eye(c.shape[0])), transA=True) for c in self.C]   # C^T on the device
 
     # ---- level views of an assembled (W, D, D) environment ----
     def _levels(self, t: DTensor, chis):
