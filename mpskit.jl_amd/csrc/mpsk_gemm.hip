@@ -99,6 +99,27 @@ template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
 
 // Accumulate the flattened k-tile range [ktb, kte) (k-tile t = segment t / tps, offset (t % tps) * BK)
 // of the output tile at (m0, n0) into the MFMA accumulators.  Ends with a barrier: LDS is reusable.
+// Compile-time experiment (-DMPSK_MFMA_4X4X4=1): the k loop on v_mfma_f64_4x4x4 instead of v_mfma_f64_16x16x4.
+// MEASURED AND REJECTED on MI355X: bit-correct (all 142 GPU tests pass) but 42 instead of 56 TFLOP/s on the dAC stage
+// kernels at D = 1024 (bench.py 0.446 instead of 0.545 sweeps/s), although the LDS-fed microbenchmark
+// (tools/mfma_f64_lds.hip) sustains 68 vs 46 TFLOP/s for the two shapes: four times the MFMA issue slots plus the DPP
+// rotations do not fit between the scheduling barriers that keep the ds_reads ahead of the MFMAs.
+#ifndef MPSK_MFMA_4X4X4
+#define MPSK_MFMA_4X4X4 0
+#endif
+#ifndef MPSK_ROT1            // DPP row_ror amounts that bring block q + 1 / q + 3 of a 16-lane row into block q
+#define MPSK_ROT1 0x12C
+#define MPSK_ROT3 0x124
+#endif
+// rotate a double inside every 16-lane row (DPP row_ror:n = control 0x120 | n on the two 32-bit halves)
+template <int CTRL>
+__device__ __forceinline__ double row_rot(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
 __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double* __restrict__ Ab,
                                                 const double* __restrict__ Bb, int m0, int n0, int ktb, int kte,
@@ -152,11 +173,32 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
       // keep the next k-step's ds_reads ABOVE this k-step's MFMAs (the machine scheduler otherwise sinks
       // them to their use and every MFMA group starts with s_waitcnt lgkmcnt(0) on a just-issued read)
       __builtin_amdgcn_sched_barrier(0);
+#if MPSK_MFMA_4X4X4
+      // v_mfma_f64_4x4x4 (4 independent 4x4x4 blocks q: operand lanes 16k + 4q + {i | j}, result lane 16i + 4q + j):
+      // with the B fragment as the first operand and the A fragment as the second, block q yields
+      // C[m = 4q + j][n = 4q + i]; rotating the B fragment by r blocks inside each 16-lane row (DPP row_ror) gives the
+      // column block (q + r) & 3, so 4 instructions cover the same 16 x 16 x 4 product as one v_mfma_f64_16x16x4 --
+      // out of the same two LDS fragments, at the higher issue rate this shape sustains (tools/mfma_f64_lds.hip:
+      // 68 vs 46 TFLOP/s out of LDS).  acc[i][j][r] is un-rotated into the 16x16x4 register layout after the k loop.
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const double b0 = bf[cb][j];
+        const double b1 = row_rot<MPSK_ROT1>(b0), b2 = row_rot<0x128>(b0), b3 = row_rot<MPSK_ROT3>(b0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          acc[i][j][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(b0, af[cb][i], acc[i][j][0], 0, 0, 0);
+          acc[i][j][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(b1, af[cb][i], acc[i][j][1], 0, 0, 0);
+          acc[i][j][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(b2, af[cb][i], acc[i][j][2], 0, 0, 0);
+          acc[i][j][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(b3, af[cb][i], acc[i][j][3], 0, 0, 0);
+        }
+      }
+#else
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < kte) {
@@ -166,6 +208,24 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
     __syncthreads();
     kt = kt2; seg = seg2;
   }
+#if MPSK_MFMA_4X4X4
+  {  // register r of a lane in block q holds the column block (q + r) & 3: bring block rg into register rg
+    const int q = (threadIdx.x >> 2) & 3;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const d4 v = acc[i][j];
+        d4 o;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = (rg - q) & 3;
+          o[rg] = r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3]));
+        }
+        acc[i][j] = o;
+      }
+  }
+#endif
 }
 
 // XCD-ordered linear tile index t -> tile coordinates.  Tiles [x*q, (x+1)*q) run on XCD x (q = ntiles / 8).
