@@ -103,7 +103,8 @@ template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
 // MEASURED AND REJECTED on MI355X: bit-correct (all 142 GPU tests pass) but 42 instead of 56 TFLOP/s on the dAC stage
 // kernels at D = 1024 (bench.py 0.446 instead of 0.545 sweeps/s), although the LDS-fed microbenchmark
 // (tools/mfma_f64_lds.hip) sustains 68 vs 46 TFLOP/s for the two shapes: four times the MFMA issue slots plus the DPP
-// rotations do not fit between the scheduling barriers that keep the ds_reads ahead of the MFMAs.
+// rotations cost more than the shape's higher issue rate returns -- with the scheduling barriers that keep the ds_reads
+// ahead of the MFMAs and without them (-DMPSK_MFMA_4X4X4_FREE_SCHED=1: 41-42 TFLOP/s as well).
 #ifndef MPSK_MFMA_4X4X4
 #define MPSK_MFMA_4X4X4 0
 #endif
@@ -172,7 +173,9 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
       }
       // keep the next k-step's ds_reads ABOVE this k-step's MFMAs (the machine scheduler otherwise sinks
       // them to their use and every MFMA group starts with s_waitcnt lgkmcnt(0) on a just-issued read)
+#if !(MPSK_MFMA_4X4X4 && MPSK_MFMA_4X4X4_FREE_SCHED)
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #if MPSK_MFMA_4X4X4
       // v_mfma_f64_4x4x4 (4 independent 4x4x4 blocks q: operand lanes 16k + 4q + {i | j}, result lane 16i + 4q + j):
       // with the B fragment as the first operand and the A fragment as the second, block q yields
@@ -199,7 +202,9 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
 #endif
+#if !(MPSK_MFMA_4X4X4 && MPSK_MFMA_4X4X4_FREE_SCHED)
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if (t + 1 < kte) {
       la.store(sA + (cur ^ 1) * IA::SIZE, tid);
