@@ -113,6 +113,19 @@ class CpuBackend:
         o = self.empty(GL.shape[1], x.shape[1], x.shape[2]) if out is None else out
         return self._set(o, y)
 
+    def dAC2(self, H1, H2, GL, GR, x2, out=None):
+        self._count("dAC2")
+        y = mo.dAC2(self.download(x2), H1.oracle, H2.oracle, self._env(GL, H1.chil), self._env(GR, H2.chir))
+        o = self.empty(GL.shape[1], x2.shape[1], GR.shape[2], x2.shape[3]) if out is None else out
+        return self._set(o, y)
+
+    def tsplit(self, theta, max_keep=0, trunc_err=0.0):
+        """Backend.tsplit: (al, c, ar, S[:k], disc) with c = diag(S) (the GPU path returns a triangular c for large theta)."""
+        self._count("tsplit")
+        U, S, Vh, k, disc = self.tsvd(theta, max_keep=max_keep, trunc_err=trunc_err)
+        u, s, vh = self.download(U), self.download(S).reshape(-1), self.download(Vh)
+        return self.upload(u[:, :k]), self.upload(np.diag(s[:k])), self.upload(vh[:k, :]), s[:k].copy(), disc
+
     def dC(self, GL, GR, c, out=None):
         self._count("dC")
         W = GL.shape[0]
