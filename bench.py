@@ -169,7 +169,9 @@ def main():
                     "launches": top["launches"], "avg_ms": round(top["avg_ms"], 5),
                     "flops_per_launch": top["flops"] / top["launches"], "traffic": None}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):                     # HBM bytes per launch from a separate rocprofv3 --pmc run
+        # HBM bytes per launch from a separate rocprofv3 --pmc run of the north-star point (tools/dac_only.py: D = 1024,
+        # one GPU); for any other workload the counters were not collected -> null
+        if os.path.exists(pmc) and args.D == 1024 and world == 1:
             try:
                 roofline["traffic"] = json.load(open(pmc)).get(top["kernel"])
             except Exception:
