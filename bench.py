@@ -92,11 +92,9 @@ def main():
     ap.add_argument("--D", type=int, default=1024)
     ap.add_argument("--matvecs", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard-env", action="store_true",
-                    help="also shard the environment updates over the ranks (dist.ShardedTransfer: all-reduce / all-gather "
-                         "per update); opt-in until validated on a multi-GPU node")
     ap.add_argument("--force-shard", action="store_true",
-                    help="run the sharded-matvec plumbing even with one rank (exercises the RCCL path on a 1-GPU box)")
+                    help="run the sharded sweep (blocked vectors, storage-sharded environments, RCCL collectives) even with "
+                         "one rank: exercises the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,7 +116,7 @@ def main():
 
     import mpskit_jl_amd as mk
     from mpskit_jl_amd import algorithms as alg, krylov
-    from mpskit_jl_amd.dist import shard_wrapper
+    from mpskit_jl_amd.dist import Comm, ShardedFinEnv
 
     be = mk.Backend(local_rank)
     L, D, d = args.L, args.D, 2
@@ -126,14 +124,13 @@ def main():
     W = H[0].Wl
     rng = np.random.default_rng(20240213)          # same seed on every rank -> identical replicas
     psi = mk.FiniteMPS.random(L, d, D, rng, normalize=True, be=be)
-    tops = None
-    if args.shard_env and (world > 1 or args.force_shard):
-        from mpskit_jl_amd.dist import ShardedTransfer, DevicePlumbing
-        tops = ShardedTransfer(DevicePlumbing(be), world, rank, force=args.force_shard)
-    envs = mk.FinEnv(psi, H, transfer_ops=tops)
+    sharded = world > 1 or args.force_shard
+    comm = Comm(world, rank, force_collective=args.force_shard) if sharded else None
+    # N > 1: bond-sharded sweep -- storage-sharded environments (1/N per GPU), blocked Krylov vectors, one in-place
+    # all-gather per matvec, one all-reduce per left-environment update, one gather per right-environment use
+    envs = ShardedFinEnv(psi, H, comm, force=args.force_shard) if sharded else mk.FinEnv(psi, H)
     eig = mk.Arnoldi(fixed_matvecs=args.matvecs, krylovdim=max(args.matvecs, 2))
     ws = krylov.KrylovWorkspace(be)
-    wrap = shard_wrapper(be, world, rank, force=args.force_shard) if (world > 1 or args.force_shard) else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -142,14 +139,14 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        alg.dmrg_sweep(psi, H, envs, eig, ws, wrap)
+        alg.dmrg_sweep(psi, H, envs, eig, ws)
     be.prof_enable(True)
     qr0 = be.qr_stats()
     barrier()
     t0 = time.perf_counter()
     eps = None
     for _ in range(args.steps):
-        eps = alg.dmrg_sweep(psi, H, envs, eig, ws, wrap)
+        eps = alg.dmrg_sweep(psi, H, envs, eig, ws)
     barrier()
     dt = time.perf_counter() - t0
     be.prof_enable(False)
@@ -206,9 +203,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Heisenberg S=1/2 FiniteMPS L={L} D={D} d=2 W={W} fp64, 1-site DMRG sweep "
                                    f"(2L-2 site updates), fixed Krylov budget {args.matvecs} matvecs/site",
-                       "parallelism": "single GPU" if world == 1 else f"bond-index sharded matvec x{world} "
-                                                                        "(one RCCL all-gather per matvec)"
-                                                                        + (", sharded environment updates" if tops else "")},
+                       "parallelism": "single GPU" if not sharded else
+                       f"bond index sharded x{world}: storage-sharded environments (1/{world} per GPU), one in-place RCCL "
+                       "all-gather per matvec, one all-reduce per left-environment update, gauge steps replicated"},
             "dAC_tflops": None if dac_tflops is None else round(dac_tflops, 3),
             "dAC_frac_of_fp64_mfma_peak": None if dac_tflops is None else round(dac_tflops / FP64_MFMA_PEAK_TFLOPS, 4),
             "max_galerkin_last_sweep": None if eps is None else float(max(eps)),

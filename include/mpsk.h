@@ -22,7 +22,13 @@
  *  - one mpsk_ctx = one device + one HIP stream + a private workspace.  Calls on a ctx are
  *    asynchronous on its stream; functions that return a host scalar synchronise.  Distinct
  *    ctxs may be driven concurrently from distinct host threads (the reference applies its
- *    operators from several Julia tasks: vumps.jl:39-49,78-86).
+ *    operators from several Julia tasks: vumps.jl:39-49,78-86); give each its own stream
+ *    (mpsk_ctx_set_stream) if the work is to overlap.  ONE ctx must not be used from two threads
+ *    at once.  The only process-wide state of the library (per-device kernel attributes, the
+ *    split-K workspace table keyed by (device, stream), the event profile) is atomic /
+ *    mutex-protected; tests/test_gpu_threads.py drives two ctxs from two threads and compares
+ *    bit-for-bit with the serial run.  mpsk_ctx_force_tile and mpsk_prof_* are process-wide
+ *    diagnostics.
  *  - dtype: this round implements MPSK_F64 (real fp64 MFMA path).  MPSK_C128 is reserved and
  *    returns MPSK_ERR_UNSUPPORTED.
  */
@@ -50,6 +56,8 @@ const char* mpsk_last_error(void);
 int mpsk_ctx_create(int device, mpsk_ctx** out);
 int mpsk_ctx_destroy(mpsk_ctx* ctx);
 int mpsk_ctx_set_stream(mpsk_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = default */
+int mpsk_ctx_get_stream(mpsk_ctx* ctx, void** hip_stream);
+int mpsk_ctx_get_device(mpsk_ctx* ctx, int* device);
 int mpsk_ctx_synchronize(mpsk_ctx* ctx);
 int mpsk_ctx_workspace_reserve(mpsk_ctx* ctx, size_t bytes);   /* pre-size the private workspace */
 /* QRpos algorithm: 0 auto (shifted CholeskyQR3 on the GEMM core; when the device flags an ill-conditioned /
@@ -98,6 +106,13 @@ int mpsk_mposlice_dims(const mpsk_mposlice* s, int* Wl, int* Wr, int* d);
  *   GR: Wr slabs [Dr, Dr];  x: [Dl, d, Dr];  y: [Dlo, d, Dr]. */
 int mpsk_dAC(mpsk_ctx* ctx, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL,
              const void* GR, const void* x, void* y);
+/* The same matvec with x in the bond-sharded ("blocked") vector layout of the multi-GPU path: x is given
+ * as nblk row blocks, block q = x[q Dl/nblk : (q+1) Dl/nblk, :, :] stored as a contiguous [Dl/nblk, d, Dr] tensor at
+ * offset q (Dl/nblk) d Dr -- exactly what an all-gather of the ranks' output row blocks produces, so the Krylov vectors
+ * of a sharded eigensolve never have to be re-interleaved.  y: [Dlo, d, Dr] (this rank's row block; the caller points
+ * it INTO the blocked destination vector and all-gathers in place).  nblk == 1 is mpsk_dAC. */
+int mpsk_dAC_blocked(mpsk_ctx* ctx, const mpsk_mposlice* H, int nblk, int Dlo, int Dl, int Dr, const void* GL,
+                     const void* GR, const void* xblk, void* y);
 /* mpsk_dC == dC(x, leftenv::Vector, rightenv::Vector)   derivatives.jl:171-193
  *   y[p,q] = sum_w GL[w][p,a] c[a,b] GR[w][b,q] */
 int mpsk_dC(mpsk_ctx* ctx, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
@@ -140,8 +155,11 @@ int mpsk_qrlq_pair(mpsk_ctx* ctx, int m, int n, const void* A1, int lda1, void* 
 int mpsk_lqpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq);
 /* thin SVD of theta (m x n): theta = U diag(S) Vh, S descending.  U: m x kmax, S: kmax, Vh: kmax x n
  * buffers with kmax = min(m, n).  Truncation (TensorKit truncdim & truncerr, dmrg.jl:75,96):
- * keep at most max_keep (<= 0: no limit) values and drop the tail while
- * ||S_dropped||_2 <= trunc_err * ||S||_2.  *kept / *disc_norm are written on the host (sync). */
+ * keep at most max_keep (<= 0: no limit) values and drop the tail while ||S_dropped||_2 <= trunc_err -- an ABSOLUTE
+ * bound, as TensorKit 0.12's truncerr(eps) (p = 2) applies it [restated from the published TensorKit source, which the
+ * reference does not vendor: parity unpinned; equal to the relative rule for the normalised theta of DMRG2 / IDMRG2 /
+ * real-time TDVP2].  *kept / *disc_norm are written on the host (sync).
+ * Returns MPSK_ERR_HIP with "did not converge" if the Jacobi iteration is not orthogonal to 1e-9 after 40 sweeps. */
 int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, int ldu, void* S, void* Vh,
               int ldv, int max_keep, double trunc_err, int* kept, double* disc_norm);
 /* Truncated two-site split theta (m x n, min(m, n) > 64) ~ AL (m x k) . C (k x k) . AR (k x n): what dmrg.jl:96-104 /

@@ -49,6 +49,10 @@ SIGNATURES = {
     "mpsk_mposlice_dims": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mpsk_dAC": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                  C.c_void_p],
+    "mpsk_dAC_blocked": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                         C.c_void_p, C.c_void_p],
+    "mpsk_ctx_get_stream": [C.c_void_p, c_void_pp],
+    "mpsk_ctx_get_device": [C.c_void_p, C.POINTER(C.c_int)],
     "mpsk_dC": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                 C.c_void_p],
     "mpsk_dAC2": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -166,32 +166,37 @@ def find_groundstate(psi, H, alg=None, envs=None):
     raise TypeError(f"unknown algorithm {alg!r}")
 
 
-def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None, wrap=None):
+def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
     """One full DMRG sweep, pos in [1:L-1; L:-1:2] (dmrg.jl:33-38): per site one eigsolve with the
     effective Hamiltonian, one galerkin evaluation, and the lazy gauge / environment updates that
     the next site triggers.  Returns the per-site galerkin errors.
-    wrap: optional h -> h' (dist.shard_wrapper: bond-sharded multi-GPU matvec)."""
+    envs: FinEnv, or dist.ShardedFinEnv (bond-sharded multi-GPU sweep): its `site_op` returns a matvec on vectors in
+    the blocked layout together with `encode` / `decode` (rows <-> rank blocks, once per site visit)."""
     be = psi.be
     L = len(psi)
     eps_s = [0.0] * L
     for pos in list(range(0, L - 1)) + list(range(L - 1, 0, -1)):
-        h = ddAC(pos, psi, H, envs)
-        if wrap is not None:
-            h = wrap(h)
+        h = envs.site_op(pos, psi) if hasattr(envs, "site_op") else ddAC(pos, psi, H, envs)
         ac_old = psi.AC(pos)
+        enc = getattr(h, "encode", None)
+        x0 = ac_old if enc is None else enc(ac_old)
         # the eigensolver's first matvec is H_AC (AC_old / |AC_old|): exactly the vector calc_galerkin of the old
         # tensor normalises (toolbox.jl:18), so it is captured instead of applying H_AC to AC_old a second time
         g = be.empty(*ac_old.shape)
-        _, vec = fixedpoint(be, h, ac_old, eigalg, ws, first_image=g)
-        if psi.ALs[pos] is None:
+        _, vec = fixedpoint(be, h, x0, eigalg, ws, first_image=g)
+        if enc is not None:
+            vec, g = h.decode(vec), h.decode(g)
+        if psi.ALs[pos] is None and pos < L - 1:
             # right-moving visit: leftorth(old AC) (galerkin projector) and leftorth(new AC) (next AL)
             # are both due -> issue them together; same state as the lazy views would produce
             al_old = psi.set_AC_with_leftorth(pos, vec)
-            eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old, g))
         else:
-            # left-moving visit: leftorth(old AC) and rightorth(new AC) are both due -> one paired call
-            al_old = psi.set_AC_with_rightorth(pos, vec)
-            eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old, g))
+            # left-moving visit (and the turning point pos = L-1, where the next step is a rightorth): the galerkin
+            # projector is leftorth(old AC) (cached AL[pos] if the state holds it), the new AC is stored as is
+            # and gauged lazily when the next site asks for AR[pos] (orthoview.jl:27-31, 49-54)
+            al_old = psi.AL(pos)
+            psi.set_AC(pos, vec)
+        eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old, g))
     return eps_s
 
 

@@ -50,7 +50,9 @@ class DTensor:
 class Backend:
     """One mpsk_ctx on one GPU.  Raises MpskError when the HIP library or a GPU is missing."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """stream: a torch.cuda.Stream to bind (default: the calling thread's current torch stream).  Two Backends on
+        two streams may be driven from two host threads at the same time (include/mpsk.h, thread-safety note)."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise MpskError("no HIP device visible: the mpskit.jl_amd product path has no CPU fallback")
@@ -60,12 +62,12 @@ class Backend:
         h = C.c_void_p()
         check(self.lib.mpsk_ctx_create(device, C.byref(h)), "mpsk_ctx_create")
         self.ctx = h
-        self.bind_stream()
+        self.bind_stream(stream)
 
-    def bind_stream(self):
+    def bind_stream(self, stream=None):
         torch = _torch()
-        s = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.mpsk_ctx_set_stream(self.ctx, C.c_void_p(s)), "mpsk_ctx_set_stream")
+        self.torch_stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        check(self.lib.mpsk_ctx_set_stream(self.ctx, C.c_void_p(self.torch_stream.cuda_stream)), "mpsk_ctx_set_stream")
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -174,6 +176,17 @@ class Backend:
         assert Dl2 == Dl and GR.shape == (H.Wr, Dr, Dr) and Wl == H.Wl and d == H.d, (GL.shape, GR.shape, x.shape)
         y = self.empty(Dlo, d, Dr) if out is None else out
         check(self.lib.mpsk_dAC(self.ctx, H.handle, Dlo, Dl, Dr, GL.ptr, GR.ptr, x.ptr, y.ptr), "mpsk_dAC")
+        return y
+
+    def dAC_blocked(self, H, GLrows: DTensor, GR: DTensor, xb: DTensor, nblk, out: DTensor = None):
+        """mpsk_dAC_blocked: x in `nblk` row blocks (dist.to_blocked), GLrows = this rank's rows (W, Dlo, Dl);
+        returns / fills y[Dlo, d, Dr] (the caller usually points `out` into the blocked destination vector)."""
+        Dl, d, Dr = xb.shape
+        Wl, Dlo, Dl2 = GLrows.shape
+        assert Dl2 == Dl and GR.shape == (H.Wr, Dr, Dr) and Wl == H.Wl and d == H.d and Dl % nblk == 0
+        y = self.empty(Dlo, d, Dr) if out is None else out
+        check(self.lib.mpsk_dAC_blocked(self.ctx, H.handle, int(nblk), Dlo, Dl, Dr, GLrows.ptr, GR.ptr, xb.ptr, y.ptr),
+              "mpsk_dAC_blocked")
         return y
 
     def dC(self, GL: DTensor, GR: DTensor, c: DTensor, out: DTensor = None):
@@ -293,6 +306,13 @@ class Backend:
             self.copy2d(m, k, U.ptr, m, al.ptr, m)
             ar = self.empty(k, n)
             self.copy2d(k, n, Vh.ptr, kmax, ar.ptr, k)
+            if k > 0 and s[k - 1] <= 1e-14 * s[0]:
+                # kept singular values at the rounding floor (rank-deficient theta with truncdim > rank): the one-sided
+                # Jacobi leaves (numerically) zero vectors there, LAPACK returns an orthonormal completion.  QRpos /
+                # LQpos (Householder for <= 64 columns) reproduce the well-defined columns and complete the rest,
+                # so al / ar stay isometries, which the lazy gauge and FinEnv assume.
+                al, _ = self.qrpos(al)
+                _, ar = self.lqpos(ar)
             return al, self.upload(np.diag(s)), ar, s, disc
         AL, Cm, AR, S = self.empty(m, kmax), self.empty(kmax, kmax), self.empty(kmax, n), self.empty(kmax)
         kept, disc = C.c_int(0), C.c_double(0.0)

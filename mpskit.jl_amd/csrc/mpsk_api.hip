@@ -93,6 +93,9 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (!c) return MPSK_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  gemm_release_stream(c->stream);     // split-K partial-tile workspaces attached to this ctx's streams
+  gemm_release_stream(c->stream2);
   for (auto& kv : c->pair_plans) mix_plan_destroy(&kv.second);
   if (c->ws) (void)hipFree(c->ws);
   if (c->d_scal) (void)hipFree(c->d_scal);
@@ -111,7 +114,23 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
 
 int mpsk_ctx_set_stream(mpsk_ctx* c, void* s) {
   REQUIRE(c, "ctx is NULL");
+  if (c->stream != (hipStream_t)s) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    gemm_release_stream(c->stream);
+  }
   c->stream = (hipStream_t)s;
+  return MPSK_OK;
+}
+
+int mpsk_ctx_get_stream(mpsk_ctx* c, void** s) {
+  REQUIRE(c && s, "NULL argument");
+  *s = (void*)c->stream;
+  return MPSK_OK;
+}
+int mpsk_ctx_get_device(mpsk_ctx* c, int* device) {
+  REQUIRE(c && device, "NULL argument");
+  *device = c->device;
   return MPSK_OK;
 }
 
@@ -313,10 +332,10 @@ extern "C" {
 // --------------------------------------------------------------------------------------------
 // derivatives
 // --------------------------------------------------------------------------------------------
-int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
-             const void* x, void* y) {
-  REQUIRE(c && H && GL && GR && x && y, "NULL argument");
-  REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+// x may be given in `nblk` row blocks (block q = rows [q Dl/nblk, (q+1) Dl/nblk) as a contiguous [Dl/nblk, d, Dr]
+// tensor): the blocks become K-segments of the stage-1 GEMM, nothing is re-interleaved (mpsk_dAC_blocked).
+static int dAC_impl(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
+                    const void* x, int nblk, void* y) {
   HIPCHK(hipSetDevice(c->device));
   const int d = H->d, Wl = H->Wl, Wr = H->Wr;
   const size_t slab = (size_t)Dlo * d * Dr;
@@ -324,8 +343,11 @@ int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const
   double* T1 = (double*)c->ws;
   double* T2 = T1 + slab * Wl;
   // stage 1: T1[w] = GL[w] * x     (batched over w)
-  GemmArgs g1 = mk((const double*)GL, (const double*)x, T1, Dlo, d * Dr, Dl, Dlo, Dl, Dlo);
+  const int kb = Dl / nblk;
+  GemmArgs g1 = mk((const double*)GL, (const double*)x, T1, Dlo, d * Dr, kb, Dlo, kb, Dlo);
   g1.batch = Wl; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.nseg = nblk;
+  for (int q = 0; q < nblk; ++q) { g1.segA[q] = (int64_t)q * kb * Dlo; g1.segB[q] = (int64_t)q * kb * d * Dr; }
   g1.tag = 1;
   HIPCHK(gemm_f64(g1, c->stream));
   // stage 2: T2[v][:,t,:] = sum_{w,s} O[w,t,s,v] T1[w][:,s,:]
@@ -339,6 +361,21 @@ int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const
   g3.tag = 1;
   HIPCHK(gemm_segments(g3, sa, sb, c->stream));
   return MPSK_OK;
+}
+
+int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
+             const void* x, void* y) {
+  REQUIRE(c && H && GL && GR && x && y, "NULL argument");
+  REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  return dAC_impl(c, H, Dlo, Dl, Dr, GL, GR, x, 1, y);
+}
+
+int mpsk_dAC_blocked(mpsk_ctx* c, const mpsk_mposlice* H, int nblk, int Dlo, int Dl, int Dr, const void* GL,
+                     const void* GR, const void* xblk, void* y) {
+  REQUIRE(c && H && GL && GR && xblk && y, "NULL argument");
+  REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  REQUIRE(nblk >= 1 && nblk <= MAXSEG && Dl % nblk == 0, "nblk must divide Dl (and be <= 32)");
+  return dAC_impl(c, H, Dlo, Dl, Dr, GL, GR, xblk, nblk, y);
 }
 
 int mpsk_dC(mpsk_ctx* c, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR, const void* cm, void* y) {
@@ -679,13 +716,13 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
     if (int rc = qrpos_dispatch(c, mm, nn, Ap, lda, Qb, mm, Rb, nn, rest)) return rc;
     hipError_t e = tsvd(nn, nn, Rb, nn, (double*)U, ldu, (double*)S, (double*)Vh, ldv, max_keep, trunc_err, kept,
                         disc_norm, rest, c->stream, &err, &c->last_svd_sweeps, Qb, mm, mm, transposed, c->stream2);
-    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
     return MPSK_OK;
   }
   if (int rc = ensure_ws(c, tsvd_workspace_bytes(m, n))) return rc;
   hipError_t e = tsvd(m, n, (const double*)theta, ldt, (double*)U, ldu, (double*)S, (double*)Vh, ldv, max_keep,
                       trunc_err, kept, disc_norm, c->ws, c->stream, &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->stream2);
-  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
   return MPSK_OK;
 }
 
@@ -730,7 +767,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   std::string err;
   hipError_t e = tsvd(nn, nn, Rb, nn, Y, nn, (double*)S, nullptr, 1, max_keep, trunc_err, kept, disc_norm, c->ws, c->stream,
                       &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, nullptr, /*vfree=*/1);
-  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
   const int k = *kept;
   REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");
   if (!transposed) {

@@ -349,12 +349,8 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
     hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, s, Gw, npad, n, factor);
   }
   const int nb = npad / CB;
-  static bool step_attr = false;
-  if (!step_attr) {
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cq_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)CQ_STEP_LDS)) != hipSuccess) return e;
-    step_attr = true;
-  }
+  static std::atomic<uint64_t> step_attr{0};
+  if ((e = ensure_dyn_smem(step_attr, reinterpret_cast<const void*>(cq_step_kernel), CQ_STEP_LDS)) != hipSuccess) return e;
   for (int k = 0; k < nb; ++k) {            // one fused launch per block column (see cq_step_kernel)
     const int nt = nb - k;
     const int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt;

@@ -360,12 +360,8 @@ hipError_t qrpos(int m, int n, const double* A, int lda, double* Q, int ldq, dou
   hipError_t e;
   if ((e = hipMemcpy2DAsync(Aw, sizeof(double) * m, A, sizeof(double) * lda, sizeof(double) * m, n,
                             hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
-  static bool attr = false;
-  if (!attr) {
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, QR_LDS_DOUBLES * 8)) != hipSuccess) return e;
-    attr = true;
-  }
+  static std::atomic<uint64_t> attr{0};
+  if ((e = ensure_dyn_smem(attr, reinterpret_cast<const void*>(qr_block_kernel), QR_LDS_DOUBLES * 8)) != hipSuccess) return e;
   auto gemm = [&](const double* a, const double* b, double* c, int M, int N, int K, int64_t la, int64_t lb, int64_t lc,
                   int tA, double alpha, double beta) {
     GemmArgs g;

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "mpsk_internal.h"
@@ -449,15 +450,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_f64_kernel(GemmArgs g) {
 
 // ---- event profile of the tagged (matvec) launches ---------------------------------------------
 struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned, sk; };
-static bool g_prof_on = false;
+// The profile is process-wide (every ctx's tagged launches land in one list); the list is mutex-protected because
+// distinct ctxs may launch from distinct host threads.
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 
 void gemm_prof_enable(bool on) {
-  if (on && !g_prof_on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (on && !g_prof_on.load()) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
   }
-  g_prof_on = on;
+  g_prof_on.store(on);
+}
+static void prof_push(const ProfRec& r) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(r);
 }
 
 // JSON list of {kernel, launches, total_ms, avg_ms, flops}; synchronises the device.
@@ -465,6 +474,7 @@ std::string gemm_prof_summary() {
   (void)hipDeviceSynchronize();
   struct Agg { long n = 0; double ms = 0, flops = 0; };
   std::map<std::string, Agg> agg;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
@@ -493,13 +503,8 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   using LB = TileLoader<BN, !TB, ALIGNED>;
   constexpr size_t smem = (2 * LA::Img::SIZE + 2 * LB::Img::SIZE) * sizeof(double);
   auto kern = gemm_f64_kernel<BM, BN, TA, TB, ALIGNED>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_set{0};
+  if (hipError_t e = ensure_dyn_smem(attr_set, reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return e;
   const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
   dim3 grid(tilesM * tilesN, g.batch, 1);
   if constexpr ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) {
@@ -509,15 +514,11 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
       const int nwg = (int)((U + g.sk_units - 1) / g.sk_units);
       const void* kp = (g.tag == 1 && !TA && !TB) ? reinterpret_cast<const void*>(dac_gemm_sk_f64_kernel<BM, BN, ALIGNED>)
                                                    : reinterpret_cast<const void*>(gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>);
-      static bool sattr[2] = {false, false};
+      static std::atomic<uint64_t> sattr[2];
       const int which = (g.tag == 1 && !TA && !TB) ? 1 : 0;
-      if (!sattr[which]) {
-        hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        sattr[which] = true;
-      }
+      if (hipError_t e = ensure_dyn_smem(sattr[which], kp, smem); e != hipSuccess) return e;
       ProfRec r;
-      const bool prof = g_prof_on && which == 1;
+      const bool prof = g_prof_on.load(std::memory_order_relaxed) && which == 1;
       if (prof) {
         r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 1;
         (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
@@ -529,29 +530,25 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
       } else {
         hipLaunchKernelGGL((gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>), dim3(nwg), dim3(NTHREADS), smem, s, g);
       }
-      if (prof) { (void)hipEventRecord(r.e1, s); g_prof.push_back(r); }
       hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN>), dim3(tilesM * tilesN * g.batch), dim3(256), 0, s, g);
+      // the event window covers the split GEMM AND its fixup launch: the flops credited are those of the whole stage
+      if (prof) { (void)hipEventRecord(r.e1, s); prof_push(r); }
       return hipGetLastError();
     }
   }
   if constexpr (!TA && !TB) {
     if (g.tag == 1) {
       auto dk = dac_gemm_f64_kernel<BM, BN, ALIGNED>;
-      static bool dattr = false;
-      if (!dattr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dk),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        dattr = true;
-      }
-      if (g_prof_on) {
+      static std::atomic<uint64_t> dattr{0};
+      if (hipError_t e = ensure_dyn_smem(dattr, reinterpret_cast<const void*>(dk), smem); e != hipSuccess) return e;
+      if (g_prof_on.load(std::memory_order_relaxed)) {
         ProfRec r;
         r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 0;
         (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
         (void)hipEventRecord(r.e0, s);
         hipLaunchKernelGGL(dk, grid, dim3(NTHREADS), smem, s, g);
         (void)hipEventRecord(r.e1, s);
-        g_prof.push_back(r);
+        prof_push(r);
       } else {
         hipLaunchKernelGGL(dk, grid, dim3(NTHREADS), smem, s, g);
       }
@@ -582,30 +579,47 @@ static void choose_tile(int M, int N, int batch, int* bm, int* bn) {
   }
 }
 
-static int g_force_bm = 0, g_force_bn = 0;
+static std::atomic<int> g_force_bm{0}, g_force_bn{0};   // benchmarking knob (process-wide)
 void gemm_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 // Stream-K is implemented and parity-tested but OFF by default: on MI355X it measured no gain over
 // the data-parallel 64x64 tiling (D = 1024: 47.5 vs 47.8-50.4 TF/s, tools/bench_dac.py A/B) -- the
 // 128x128 stream-K body sits at the 256-VGPR cap and the fixup pass eats the balance it buys.
 // MPSK_STREAMK=1 enables it (single-stream use only: the partial-tile workspace is per device).
-static bool g_sk_enabled = (getenv("MPSK_STREAMK") != nullptr) && (getenv("MPSK_STREAMK")[0] == '1');
+static std::atomic<bool> g_sk_enabled{(getenv("MPSK_STREAMK") != nullptr) && (getenv("MPSK_STREAMK")[0] == '1')};
 void gemm_enable_streamk(bool on) { g_sk_enabled = on; }
 static bool g_xcd_grid_enabled = (getenv("MPSK_XCDGRID") == nullptr) || (getenv("MPSK_XCDGRID")[0] != '0');
 static bool g_splitk_enabled = (getenv("MPSK_SPLITK") == nullptr) || (getenv("MPSK_SPLITK")[0] != '0');
 constexpr size_t SK_WS_DOUBLES = (size_t)1024 * 128 * 128 / 2;   // 512 slots of 128x128 == 2048 slots of 64x64
-// partial-tile workspace: one per (device, stream) so that concurrent streams never share slots;
-// allocated on first use, never freed (64 MiB each)
+// partial-tile workspace: one per (device, stream) so that concurrent streams never share slots (launches on ONE
+// stream are ordered, so ctxs that share a stream may share its slots); allocated on first use (64 MiB each), freed by
+// gemm_release_stream when the owning ctx is destroyed.  The table is mutex-protected: distinct ctxs launch from
+// distinct host threads.
+static std::mutex g_skws_mu;
+static std::map<std::pair<int, hipStream_t>, double*> g_skws;
 static double* sk_workspace(hipStream_t s) {
-  static std::map<std::pair<int, hipStream_t>, double*> ws;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_skws_mu);
   auto key = std::make_pair(dev, s);
-  auto it = ws.find(key);
-  if (it != ws.end()) return it->second;
+  auto it = g_skws.find(key);
+  if (it != g_skws.end()) return it->second;
   double* p = nullptr;
-  if (hipMalloc(&p, SK_WS_DOUBLES * sizeof(double)) != hipSuccess) p = nullptr;
-  ws[key] = p;
+  if (hipMalloc(&p, SK_WS_DOUBLES * sizeof(double)) != hipSuccess) return nullptr;
+  g_skws[key] = p;
   return p;
+}
+void gemm_release_stream(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  double* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_skws_mu);
+    auto it = g_skws.find(std::make_pair(dev, s));
+    if (it == g_skws.end()) return;
+    p = it->second;
+    g_skws.erase(it);
+  }
+  if (p) (void)hipFree(p);
 }
 
 hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
@@ -618,7 +632,7 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   choose_tile(g.M, g.N, g.batch, &bm, &bn);
   g.sk_units = 0;
   g.sk_ws = nullptr;
-  if (g_force_bm) { bm = g_force_bm; bn = g_force_bn; }
+  if (g_force_bm.load()) { bm = g_force_bm.load(); bn = g_force_bn.load(); }
   else {
     const int KT = ((g.K + BK - 1) / BK) * g.nseg;
     const int64_t Tb = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;

@@ -3,10 +3,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include <vector>
 #include <string>
 
 namespace mpsk {
+
+// Once-per-device hipFuncSetAttribute(MaxDynamicSharedMemorySize).  `done` is a static bit mask owned by the call site
+// (one bit per device ordinal); distinct ctxs may be driven from distinct host threads, so the flag is atomic -- a race
+// only repeats the idempotent call.
+inline hipError_t ensure_dyn_smem(std::atomic<uint64_t>& done, const void* kernel, size_t bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  done.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 constexpr int MAXSEG = 32;
 
@@ -40,6 +56,9 @@ struct GemmArgs {
 
 hipError_t gemm_f64(const GemmArgs& g, hipStream_t s);
 void gemm_force_tile(int bm, int bn);
+// frees the split-K partial-tile workspace attached to (current device, stream); called when a ctx that owns or was
+// bound to the stream is destroyed (the stream must be idle)
+void gemm_release_stream(hipStream_t s);
 void gemm_enable_streamk(bool on);
 void gemm_prof_enable(bool on);
 std::string gemm_prof_summary();

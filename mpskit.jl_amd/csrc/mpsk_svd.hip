@@ -482,6 +482,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   if (const char* ev = getenv("MPSK_SVD_INNER")) { inner_sweeps = atoi(ev); if (inner_sweeps < 1) inner_sweeps = 1; }
   const int rounds = (P == 1) ? 1 : 2 * P - 1;
   unsigned long long hflag = 0;
+  double mx_last = 0.0;
   // Two streams: the V accumulation of round r (bandwidth-bound, needs only W_r) runs on s2 while the main
   // stream already forms the Gram matrices / rotations of round r+1 (latency-bound, 1 workgroup per pair).
   // W is double-buffered; evW[b]: W_b written (s -> s2), evV[b]: W_b consumed by the V update (s2 -> s).
@@ -610,6 +611,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     double mx;
     std::memcpy(&mx, &hflag, sizeof(double));
     if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] sweep %d: max |cos| = %.3e (tol %.1e)\n", sweeps, mx, tol);
+    mx_last = mx;
     if (mx <= tol) break;
     // Quadratic convergence: a sweep that STARTED with every |cos| <= 1e-9 leaves them at the rounding floor,
     // so the verification sweep (full cost, identity rotations) is skipped.
@@ -621,6 +623,14 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   drop_events();
   drop_group_events();
   if (sweeps_out) *sweeps_out = sweeps;
+  if (!(mx_last <= 1.0e-9)) {               // 40 sweeps without reaching the quadratic regime: the factors would not be isometries
+    if (err) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "block-Jacobi SVD did not converge: max |cos| = %.3e after %d sweeps", mx_last, sweeps);
+      *err = buf;
+    }
+    return hipErrorNotReady;
+  }
   if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] %d x %d: P=%d Q=%d rounds/sweep=%d sweeps=%d\n", mm, nn, P, Q, rounds, sweeps);
 
   // singular values, sorting, truncation (host)
@@ -637,10 +647,14 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   int k = kmax;
   if (max_keep > 0 && max_keep < k) k = max_keep;
   if (trunc_err > 0.0) {
-    // drop the tail while ||dropped||_2 <= trunc_err * ||S||_2   (TensorKit truncerr, p = 2)
+    // drop the tail while ||dropped||_2 <= trunc_err, an ABSOLUTE bound (TensorKit 0.12 `truncerr(eps)`, p = 2: its
+    // _truncate! compares the p-norm of the discarded values with eps itself.  TensorKit is not vendored in the reference
+    // tree, so this is restated from the published source: "parity unpinned", include/mpsk.h).  The two-site drivers
+    // normalise theta before the split (eigenvectors; unitary real-time steps), where absolute == relative.
     double tail2 = 0.0;
     for (int i = k; i < kmax; ++i) tail2 += sv[i] * sv[i];
-    while (k > 1 && tail2 + sv[k - 1] * sv[k - 1] <= trunc_err * trunc_err * tot2) { tail2 += sv[k - 1] * sv[k - 1]; --k; }
+    while (k > 1 && tail2 + sv[k - 1] * sv[k - 1] <= trunc_err * trunc_err) { tail2 += sv[k - 1] * sv[k - 1]; --k; }
+    (void)tot2;
   }
   double disc2 = 0.0;
   for (int i = k; i < kmax; ++i) disc2 += sv[i] * sv[i];

@@ -1,20 +1,37 @@
-"""Multi-GPU: bond-index sharding of the effective-Hamiltonian matvec (partition B).
+"""Multi-GPU: bond-index sharding of the DMRG site update, one process per GPU.
 
-One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).  The output bond
-index a' of  y[a',t,b'] = sum GL[w][a',a] x[a,s,b] O[w,t,s,v] GR[v][b,b']  is block-partitioned:
-rank p owns rows [p*D/P, (p+1)*D/P) of every left-environment slab, computes y[a'_p,:,:] with the
-SAME kernels (mpsk_dAC with Dlo = D/P: both GEMM stages shrink by 1/P) and ONE collective per
-matvec (all-gather of D*d*D/P doubles per rank) completes y on every rank; no reduction, so every
-rank holds bit-identical iterates and the replicated host-side Krylov loop stays in lock-step.
-Everything else of the sweep (gauge steps, environment updates) is replicated in this round
-("replicas" for those steps; DESIGN.md lists the fully sharded environment update as next).
+Partition (B of the survey): the OUTPUT bond index a' of
+    y[a',t,b'] = sum GL[w][a',a] x[a,s,b] O[w,t,s,v] GR[v][b,b']
+is block-partitioned over the P ranks.  What lives where (D = bond dimension, n = D / P, p = rank):
 
-The partition / gather-layout logic is independent of the device plumbing so that it is covered
-by world_size-2 gloo tests on CPU (tests/test_dist_cpu.py) with a host stand-in for the plumbing.
+  left environments   permanently ROW-sharded: rank p stores GL[w][a'_p, :]  (W, n, D)        -> 1/P of the memory
+  right environments  stored COLUMN-sharded over the bra index: GR[w][:, a'_p]  (W, D, n)     -> 1/P of the memory;
+                      a full copy is all-gathered ONCE PER SITE VISIT (stage 3 of the matvec reads all of GR) into a
+                      transient buffer (at most two alive)
+  Krylov vectors      replicated, in the BLOCKED layout [P][n, d, D] (rank blocks back to back): the local matvec
+                      (mpsk_dAC_blocked: the blocks are K-segments of the stage-1 GEMM) writes this rank's block
+                      straight into the destination vector and ONE in-place all-gather completes it -- no per-matvec
+                      allocation, no re-interleave kernels; vector arithmetic (dots, axpys, Gram-Schmidt) is layout
+                      agnostic.  A tensor is converted rows <-> blocks once per site visit (encode / decode).
+  environment update  transfer_left : all three stages on the local rows, the partial result (contraction over the
+                      sharded a') completed by ONE all-reduce, every rank keeps its rows;
+                      transfer_right: rank p computes the bra columns a'_p from the gathered input -- no reduction.
+  gauge steps (QRpos / LQpos), state tensors: replicated ("replicas only" for those steps).
+
+No reduction touches the Krylov vectors, so every rank holds bit-identical iterates and the replicated host-side
+Krylov loop stays in lock-step.  Chain-edge bonds that are too small to shard (D < P * min_block) keep replicated
+environments and run the plain matvec.
+
+Collectives go through `Comm` (torch.distributed: backend "nccl" == RCCL over xGMI; "gloo" on CPU for the
+world_size-2 tests).  A host without torch.distributed (the Julia shim) makes the same calls through
+libmpsk_comm (include/mpsk_comm.h: mpsk_comm_allgather / mpsk_comm_allreduce_sum on the ctx stream).
 """
 from __future__ import annotations
 
 import numpy as np
+
+from .backend import DTensor
+from .derivatives import MPO_ddAC
 
 
 class BondShard:
@@ -39,183 +56,312 @@ class BondShard:
         return (world > 1 or force) and D % world == 0 and D // world >= min_block
 
 
-class HostPlumbing:
-    """NumPy stand-in for the device plumbing (used by the CPU gloo tests only)."""
+class Comm:
+    """The two collectives of the sharded sweep on flat fp64 buffers (torch tensors: device memory on the GPU path,
+    host memory under the CPU stand-in).  staged=True stages them through the host over gloo so that TWO ranks can
+    share ONE GPU in tests (RCCL refuses duplicate devices)."""
 
-    def __init__(self, local_dAC):
-        self._dAC = local_dAC
+    def __init__(self, world=1, rank=0, group=None, staged=False, force_collective=False):
+        """force_collective: issue the torch.distributed calls even at world size 1 (exercises the RCCL path on a
+        one-GPU box; needs an initialised process group)."""
+        self.world, self.rank, self.group, self.staged = int(world), int(rank), group, staged
+        self.force_collective = force_collective
+        self.n_allgather = self.n_allreduce = 0
+        self.bytes_allgather = self.bytes_allreduce = 0
+        self._inplace = None
 
-    def row_block(self, env, lo, hi):          # env: ndarray (W, Dbra, Dket)
-        return np.ascontiguousarray(env[:, lo:hi, :])
+    def _dist(self):
+        import torch.distributed as dist
+        return dist
 
-    def local_dAC(self, H, GLloc, GR, x):
-        return self._dAC(H, GLloc, GR, x)
+    def all_gather_into(self, out, inp):
+        """out[r * len(inp) : (r + 1) * len(inp)] = rank r's inp.  `inp` may be the slice of `out` that belongs to
+        this rank (in place, what the matvec does)."""
+        self.n_allgather += 1
+        self.bytes_allgather += out.numel() * 8
+        if self.world == 1 and not self.force_collective:
+            n = inp.numel()
+            if out.data_ptr() + 8 * self.rank * n != inp.data_ptr():
+                out[:n].copy_(inp)
+            return out
+        dist = self._dist()
+        if self.staged:
+            import torch
+            h = inp.cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(parts, h, group=self.group)
+            out.copy_(torch.cat(parts).to(out.device))
+            return out
+        if self._inplace is None:
+            self._inplace = dist.get_backend(self.group) == "nccl"      # RCCL: sendbuff == recvbuff + rank * count
+        if not self._inplace and inp.data_ptr() == out.data_ptr() + 8 * self.rank * inp.numel():
+            inp = inp.clone()
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+        return out
 
-    def all_gather_rows(self, yloc, group, world):
+    def all_reduce_sum(self, buf):
+        self.n_allreduce += 1
+        self.bytes_allreduce += buf.numel() * 8
+        if self.world == 1 and not self.force_collective:
+            return buf
+        dist = self._dist()
+        if self.staged:
+            h = buf.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(h.to(buf.device))
+            return buf
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf
+
+    def all_reduce_scalar(self, v):
         import torch
-        import torch.distributed as dist
-        t = torch.from_numpy(np.ascontiguousarray(yloc))
-        outs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(outs, t, group=group)
-        return np.concatenate([o.numpy() for o in outs], axis=0)
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        if self.world > 1:
+            dist = self._dist()
+            if not self.staged and dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
 
 
-class DevicePlumbing:
-    """Device implementation: copy2d row-block extraction, mpsk_dAC on the local block, RCCL
-    all-gather through torch.distributed on the ctx stream, copy2d re-interleave."""
+# ---- layout helpers (device copies through mpsk_copy2d; once per site visit, never per matvec) --------------------
 
-    def __init__(self, be):
-        self.be = be
+def _sub(t: DTensor, offset, shape):
+    """DTensor view of `t` starting `offset` elements in."""
+    n = int(np.prod(shape))
+    return DTensor(t.buf[offset:offset + n], shape)
 
-    def row_block(self, env, lo, hi):
-        W, Db, Dk = env.shape
-        n = hi - lo
-        out = self.be.empty(W, n, Dk)
-        # all W slabs at once: rows [lo, hi) of a (Db x W*Dk) column-major matrix
-        self.be.copy2d(n, W * Dk, env.ptr + 8 * lo, Db, out.ptr, n)
+
+def rows_of_tensor(be, A: DTensor, lo, hi):
+    """rows [lo, hi) of the first index of A[a, s, b] as a contiguous (hi - lo, d, Dr) tensor."""
+    Dl, d, Dr = A.shape
+    n = hi - lo
+    out = be.empty(n, d, Dr)
+    be.copy2d(n, d * Dr, A.ptr + 8 * lo, Dl, out.ptr, n)
+    return out
+
+
+def rows_of_env(be, env: DTensor, lo, hi):
+    """rows [lo, hi) of every slab of env (W, Db, Dk) -> (W, hi - lo, Dk) (one launch: a (Db x W Dk) matrix)."""
+    W, Db, Dk = env.shape
+    n = hi - lo
+    out = be.empty(W, n, Dk)
+    be.copy2d(n, W * Dk, env.ptr + 8 * lo, Db, out.ptr, n)
+    return out
+
+
+def to_blocked(be, x: DTensor, P, out: DTensor = None):
+    """x[a, s, b] -> [P][n, d, Dr] row blocks back to back (same number of elements; logical shape kept)."""
+    Dl, d, Dr = x.shape
+    n = Dl // P
+    out = be.empty(Dl, d, Dr) if out is None else out
+    for q in range(P):
+        be.copy2d(n, d * Dr, x.ptr + 8 * q * n, Dl, out.ptr + 8 * q * n * d * Dr, n)
+    return out
+
+
+def from_blocked(be, xb: DTensor, P, out: DTensor = None):
+    Dl, d, Dr = xb.shape
+    n = Dl // P
+    out = be.empty(Dl, d, Dr) if out is None else out
+    for q in range(P):
+        be.copy2d(n, d * Dr, xb.ptr + 8 * q * n * d * Dr, n, out.ptr + 8 * q * n, Dl)
+    return out
+
+
+class ShardedSiteOp:
+    """H_AC of one site with the bond index sharded: `y = h(x, out)` on BLOCKED vectors; `encode` / `decode` convert a
+    tensor to / from the blocked layout.  One in-place all-gather per application, nothing allocated."""
+
+    def __init__(self, be, comm: Comm, H, GLrows: DTensor, GRfull: DTensor):
+        self.be, self.comm, self.o, self.leftenv, self.rightenv = be, comm, H, GLrows, GRfull
+        self.P = comm.world
+        self.n_apply = 0
+
+    def encode(self, x: DTensor, out: DTensor = None):
+        return to_blocked(self.be, x, self.P, out)
+
+    def decode(self, xb: DTensor, out: DTensor = None):
+        return from_blocked(self.be, xb, self.P, out)
+
+    def __call__(self, xb: DTensor, out: DTensor = None):
+        be, P, r = self.be, self.P, self.comm.rank
+        Dl, d, Dr = xb.shape
+        out = be.empty(Dl, d, Dr) if out is None else out
+        blk = (Dl // P) * d * Dr
+        mine = _sub(out, r * blk, (Dl // P, d, Dr))
+        be.dAC_blocked(self.o, self.leftenv, self.rightenv, xb, P, out=mine)
+        self.comm.all_gather_into(out.buf[:P * blk], mine.buf[:blk])
+        self.n_apply += 1
         return out
 
-    def local_dAC(self, H, GLloc, GR, x):
-        return self.be.dAC(H, GLloc, GR, x)
-
-    def row_block_tensor(self, A, lo, hi):
-        """rows [lo, hi) of the first index of A[a, s, b]  (column-major: a (Dl x d*Dr) matrix)."""
-        Dl, d, Dr = A.shape
-        n = hi - lo
-        out = self.be.empty(n, d, Dr)
-        self.be.copy2d(n, d * Dr, A.ptr + 8 * lo, Dl, out.ptr, n)
-        return out
-
-    def _all_reduce_flat(self, t, group):
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return t
-
-    def all_reduce_sum(self, part, group, world):
-        self._all_reduce_flat(part.buf[: part.size], group)
-        return part
-
-    def all_gather_cols(self, cols, group, world):
-        """cols: (W, Dl, n) = the column block of this rank for every slab -> (W, Dl, n * world)."""
-        W, Dl, n = cols.shape
-        gathered = self._all_gather_flat(cols, group, world)
-        out = self.be.empty(W, Dl, n * world)
-        for p in range(world):   # rank p, slab w: a contiguous Dl*n chunk -> columns [p*n, (p+1)*n) of slab w
-            self.be.copy2d(Dl * n, W, gathered.data_ptr() + 8 * p * cols.size, Dl * n,
-                           out.ptr + 8 * p * Dl * n, Dl * n * world)
-        return out
-
-    def _all_gather_flat(self, yloc, group, world):
-        """the collective itself: rank blocks back to back in one device buffer (RCCL on the current stream)."""
-        import torch
-        import torch.distributed as dist
-        gathered = torch.empty(world * yloc.size, dtype=torch.float64, device=self.be.device)
-        dist.all_gather_into_tensor(gathered, yloc.buf[: yloc.size], group=group)
-        return gathered
-
-    def all_gather_rows(self, yloc, group, world):
-        n, d, Dr = yloc.shape
-        gathered = self._all_gather_flat(yloc, group, world)
-        y = self.be.empty(n * world, d, Dr)
-        for p in range(world):   # rank p's block -> rows [p*n, (p+1)*n) of every (s, b) column
-            self.be.copy2d(n, d * Dr, gathered.data_ptr() + 8 * p * yloc.size, n, y.ptr + 8 * p * n, n * world)
-        return y
+    __mul__ = __call__
 
 
-class ShardedTransfer:
-    """Environment updates with the compute sharded over the process group ("A only where the
-    contraction index must be split (env updates with sharded AL)").  Storage stays replicated in this version.
+class ShardedFinEnv:
+    """FinEnv (src/environments/FinEnv.jl:9-145) with STORAGE sharded over the process group: same lazy,
+    identity-based invalidation as environments.FinEnv (an AL / AR that was recomputed is a new object), but a left
+    environment of a shardable bond is kept as this rank's row block and a right environment as this rank's bra-column
+    block (module docstring).  `site_op(pos, psi)` returns the matvec the sweep uses; `leftenv` / `rightenv` return
+    FULL tensors (gathered on demand: diagnostics, expectation values -- not on the sweep's hot path)."""
 
-    transfer_left :  GL'[v][b', b] = sum_{a', s', a, s, w} Ab[a', s', b'] GL[w][a', a] A[a, s, b] O[w, s', s, v].
-        Rank p takes the rows a' in its block of GL AND of Ab (all three stages shrink by 1/P) -> a partial GL'
-        of full shape; ONE all-reduce (sum) completes it on every rank.
-    transfer_right:  GR'[w][a, a'] = sum A[a, s, b] GR[v][b, b'] Ab[a', s', b'] O[w, s, s', v].
-        Rank p takes the rows a' in its block of Ab -> the COLUMNS a'_p of every output slab, no reduction;
-        ONE all-gather of the column blocks + a device re-interleave completes GR'.
-    Both leave bit-identical environments on every rank (the collectives return the same bits everywhere)."""
-
-    def __init__(self, plumbing, world, rank, group=None, min_block=64, force=False):
-        self.pl, self.be = plumbing, plumbing.be
-        self.world, self.rank, self.group, self.min_block, self.force = world, rank, group, min_block, force
-        self.n_collectives = 0
+    def __init__(self, psi, H, comm: Comm, min_block=64, force=False):
+        from .environments import _start_env
+        be = self.be = psi.be
+        self.comm, self.min_block, self.force = comm, min_block, force
+        self.P, self.rank = comm.world, comm.rank
+        L = len(psi)
+        self.H = H
+        self.opp = [H[i] for i in range(L)]
+        odim = H.odim
+        D0 = psi.AL(0).shape[0]
+        t = psi.ARs[L - 1] if psi.ARs[L - 1] is not None else psi.AL(L - 1)
+        DL = t.shape[2]
+        if self._ok(D0) or self._ok(DL):
+            raise ValueError("the chain-edge bonds must not be shardable (open boundary: dimension 1)")
+        self.leftenvs = [_start_env(be, self.opp[0].chil, D0, 0)] + [None] * L
+        self.rightenvs = [None] * L + [_start_env(be, self.opp[L - 1].chir, DL, odim - 1)]
+        self.lkind = ["rep"] + [None] * L         # 'rep' | 'row'
+        self.rkind = [None] * L + ["rep"]         # 'rep' | 'col'
+        self.ldeps = [None] * L
+        self.rdeps = [None] * L
+        self.n_transfers = 0
+        self._full_right = {}                     # bond index -> (stored tensor it was gathered from, full tensor)
 
     def _ok(self, D):
-        return BondShard.shardable(D, self.world, self.min_block, self.force)
+        return BondShard.shardable(D, self.P, self.min_block, self.force)
 
-    def transfer_left(self, H, GLin, A, Ab):
-        be = self.be
-        Dlb = Ab.shape[0]
-        if H is None or not self._ok(Dlb):
-            return be.transfer_left(H, GLin, A, Ab)
-        sh = BondShard(Dlb, self.world, self.rank)
-        GLloc = self.pl.row_block(GLin, sh.lo, sh.hi)                       # (W, Dlo, Dl)
-        Abloc = self.pl.row_block_tensor(Ab, sh.lo, sh.hi)                  # (Dlo, d, Drb)
-        part = be.transfer_left(H, GLloc, A, Abloc)
-        self.n_collectives += 1
-        return self.pl.all_reduce_sum(part, self.group, self.world)
+    def _lohi(self, D):
+        n = D // self.P
+        return self.rank * n, (self.rank + 1) * n
 
-    def transfer_right(self, H, GRin, A, Ab):
-        be = self.be
-        Dlb = Ab.shape[0]
-        if H is None or not self._ok(Dlb):
-            return be.transfer_right(H, GRin, A, Ab)
-        sh = BondShard(Dlb, self.world, self.rank)
-        Abloc = self.pl.row_block_tensor(Ab, sh.lo, sh.hi)
-        cols = be.transfer_right(H, GRin, A, Abloc)                         # (W, Dl, Dlo): columns a'_p
-        self.n_collectives += 1
-        return self.pl.all_gather_cols(cols, self.group, self.world)
+    # ---- environment updates ---------------------------------------------------------------------------------------
+    def _transfer_left(self, j, al):
+        be, Hs = self.be, self.opp[j]
+        GLin, kin = self.leftenvs[j], self.lkind[j]
+        Dl, d, Dr = al.shape
+        kout = "row" if self._ok(Dr) else "rep"
+        if kin == "rep":
+            if kout == "rep":
+                return be.transfer_left(Hs, GLin, al, al), kout
+            # replicated input, shardable output bond: rank p computes ITS rows b'_p from the bra columns b'_p
+            # (a contiguous column block of AL as a (Dl d x Dr) matrix) -- no communication
+            lo, hi = self._lohi(Dr)
+            ab = _sub(al, lo * Dl * d, (Dl, d, hi - lo))
+            return be.transfer_left(Hs, GLin, al, ab), kout
+        lo, hi = self._lohi(Dl)
+        abloc = rows_of_tensor(be, al, lo, hi)
+        part = be.transfer_left(Hs, GLin, al, abloc)               # contraction over the local rows a'_p only
+        self.comm.all_reduce_sum(part.buf[:part.size])
+        if kout == "rep":
+            return part, kout
+        lo, hi = self._lohi(Dr)
+        return rows_of_env(be, part, lo, hi), kout
+
+    def _gathered_right(self, idx):
+        """full (W, Dk, Db) copy of right environment `idx` (the bond index), gathered if stored column-sharded."""
+        t, kind = self.rightenvs[idx], self.rkind[idx]
+        if kind == "rep":
+            return t
+        hit = self._full_right.get(idx)
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        W, Dk, n = t.shape
+        full = self.be.empty(W, Dk, n * self.P)
+        slab = Dk * n
+        for w in range(W):      # slab w of the full tensor = the ranks' column blocks back to back
+            self.comm.all_gather_into(full.buf[w * slab * self.P:(w + 1) * slab * self.P], t.buf[w * slab:(w + 1) * slab])
+        if len(self._full_right) >= 2:
+            for k in sorted(self._full_right, key=lambda k: abs(k - idx), reverse=True)[:len(self._full_right) - 1]:
+                del self._full_right[k]
+        self._full_right[idx] = (t, full)
+        return full
+
+    def _transfer_right(self, j, ar):
+        be, Hs = self.be, self.opp[j]
+        GRfull = self._gathered_right(j + 1)
+        Dl, d, Dr = ar.shape
+        if not self._ok(Dl):
+            return be.transfer_right(Hs, GRfull, ar, ar), "rep"
+        lo, hi = self._lohi(Dl)
+        abloc = rows_of_tensor(be, ar, lo, hi)
+        return be.transfer_right(Hs, GRfull, ar, abloc), "col"     # (W, Dl, n): the bra columns a'_p, no reduction
+
+    def _update_right(self, ind, psi):  # FinEnv.jl:114-129
+        L = len(psi)
+        a = None
+        for i in range(L - 1, ind, -1):
+            if psi.AR(i) is not self.rdeps[i]:
+                a = i
+                break
+        if a is not None:
+            for j in range(a, ind, -1):
+                ar = psi.AR(j)
+                self.rightenvs[j], self.rkind[j] = self._transfer_right(j, ar)
+                self._full_right.pop(j, None)
+                self.rdeps[j] = ar
+                self.n_transfers += 1
+
+    def _update_left(self, ind, psi):  # FinEnv.jl:131-145
+        a = None
+        for i in range(0, ind):
+            if psi.AL(i) is not self.ldeps[i]:
+                a = i
+                break
+        if a is not None:
+            for j in range(a, ind):
+                al = psi.AL(j)
+                self.leftenvs[j + 1], self.lkind[j + 1] = self._transfer_left(j, al)
+                self.ldeps[j] = al
+                self.n_transfers += 1
+
+    # ---- the sweep's accessors ---------------------------------------------------------------------------------------
+    def site_op(self, pos, psi):
+        """H_AC of site pos: ShardedSiteOp when the left bond is sharded, the plain MPO_ddAC otherwise."""
+        self._update_left(pos, psi)
+        self._update_right(pos, psi)
+        GR = self._gathered_right(pos + 1)
+        if self.lkind[pos] == "row":
+            return ShardedSiteOp(self.be, self.comm, self.opp[pos], self.leftenvs[pos], GR)
+        return MPO_ddAC(self.be, self.opp[pos], self.leftenvs[pos], GR)
+
+    # ---- FinEnv-compatible accessors (full tensors; diagnostics) ---------------------------------------------------
+    def rightenv(self, ind, psi):
+        self._update_right(ind, psi)
+        return self._gathered_right(ind + 1)
+
+    def leftenv(self, ind, psi):
+        self._update_left(ind, psi)
+        t = self.leftenvs[ind]
+        if self.lkind[ind] == "rep":
+            return t
+        be, P = self.be, self.P
+        W, n, Dk = t.shape
+        gathered = be.empty(P, W, n, Dk)
+        self.comm.all_gather_into(gathered.buf[:gathered.size], t.buf[:t.size])
+        full = be.empty(W, n * P, Dk)
+        for q in range(P):      # rank q's rows of every slab: an (n x W Dk) matrix -> rows [q n, (q+1) n) of (D x W Dk)
+            be.copy2d(n, W * Dk, gathered.ptr + 8 * q * t.size, n, full.ptr + 8 * q * n, n * P)
+        return full
+
+    def poison(self, ind):  # FinEnv.jl:108-111
+        self.ldeps[ind] = None
+        self.rdeps[ind] = None
+
+    def bytes_local(self):
+        """bytes of environment storage held by this rank (persistent tensors; the <= 2 transient gathered right
+        environments are reported separately)."""
+        tot = sum(t.size for t in self.leftenvs if t is not None) + sum(t.size for t in self.rightenvs if t is not None)
+        return 8 * tot, 8 * sum(f.size for _, f in self._full_right.values())
 
 
-class HostStagedPlumbing(DevicePlumbing):
-    """DevicePlumbing whose collective is staged through the host over gloo: lets TWO ranks share ONE GPU (RCCL
-    refuses duplicate devices), so the device-side row-block extraction and re-interleave are exercised at
-    world_size 2 on a single-GPU box (tests/test_gpu_dist.py).  Test plumbing only."""
-
-    def _all_gather_flat(self, yloc, group, world):
-        import torch
-        import torch.distributed as dist
-        h = yloc.buf[: yloc.size].cpu()
-        outs = [torch.empty_like(h) for _ in range(world)]
-        dist.all_gather(outs, h, group=group)
-        return torch.cat(outs).to(self.be.device)
-
-    def _all_reduce_flat(self, t, group):
-        import torch.distributed as dist
-        h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
-        t.copy_(h.to(t.device))
-        return t
-
-
-class ShardedMatvec:
-    """Callable y = H_AC x with the bond index sharded over the process group."""
-
-    def __init__(self, plumbing, H, GL, GR, world, rank, group=None):
-        self.pl, self.H, self.GR = plumbing, H, GR
-        self.world, self.rank, self.group = world, rank, group
-        D = GL.shape[1]
-        self.shard = BondShard(D, world, rank)
-        self.GLloc = plumbing.row_block(GL, self.shard.lo, self.shard.hi)
-        self.n_collectives = 0
-
-    def __call__(self, x, out=None):
-        yloc = self.pl.local_dAC(self.H, self.GLloc, self.GR, x)
-        y = self.pl.all_gather_rows(yloc, self.group, self.world)
-        self.n_collectives += 1
-        if out is not None:
-            self.pl.be.axpby(1.0, y, 0.0, out)
-            return out
-        return y
-
-
-def shard_wrapper(be, world, rank, group=None, min_block=64, force=False, plumbing=None):
-    """Returns wrap(h: MPO_ddAC) -> callable used by dmrg_sweep: sites whose bond dimension is
-    shardable run the sharded matvec, the others (chain edges) run replicated."""
-    pl = DevicePlumbing(be) if plumbing is None else plumbing
-
-    def wrap(h):
-        D = h.leftenv.shape[1]
-        if not BondShard.shardable(D, world, min_block, force):
-            return h
-        return ShardedMatvec(pl, h.o, h.leftenv, h.rightenv, world, rank, group)
-    return wrap
+def memory_model(L, D, d, W, P, krylov_vectors=10):
+    """Per-GPU bytes of a sharded 1-site DMRG sweep at bulk bond dimension D: environments 1/P,
+    state / Krylov vectors replicated, matvec workspace 1/P."""
+    env = 2 * L * W * D * D * 8 / P
+    transient = 2 * W * D * D * 8
+    state = L * D * d * D * 8 * 1.05 + 3 * D * d * D * 8           # one gauge copy per site (+ the centre's AC / AL / AR)
+    krylov = (krylov_vectors + 2) * D * d * D * 8
+    work = 2 * W * (D // P) * d * D * 8
+    return {"environments": env, "gathered_right_envs": transient, "state": state, "krylov": krylov,
+            "matvec_workspace": work, "total": env + transient + state + krylov + work}

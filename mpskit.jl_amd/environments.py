@@ -28,11 +28,8 @@ class FinEnv:
     (FinEnv.jl:114-145): an AL/AR that was invalidated and recomputed is a new object, so the
     environments that depend on it are rebuilt exactly when the reference rebuilds them."""
 
-    def __init__(self, psi, H, transfer_ops=None):
-        """transfer_ops: optional object with transfer_left / transfer_right (dist.ShardedTransfer: the environment
-        update sharded over a process group); default: the backend's own kernels."""
+    def __init__(self, psi, H):
         be = self.be = psi.be
-        self.tops = be if transfer_ops is None else transfer_ops
         L = len(psi)
         self.H = H
         self.opp = [H[i] for i in range(L)]
@@ -56,7 +53,7 @@ class FinEnv:
         if a is not None:
             for j in range(a, ind, -1):
                 ar = psi.AR(j)
-                self.rightenvs[j] = self.tops.transfer_right(self.opp[j], self.rightenvs[j + 1], ar, ar)
+                self.rightenvs[j] = self.be.transfer_right(self.opp[j], self.rightenvs[j + 1], ar, ar)
                 self.rdeps[j] = ar
                 self.n_transfers += 1
         return self.rightenvs[ind + 1]
@@ -70,7 +67,7 @@ class FinEnv:
         if a is not None:
             for j in range(a, ind):
                 al = psi.AL(j)
-                self.leftenvs[j + 1] = self.tops.transfer_left(self.opp[j], self.leftenvs[j], al, al)
+                self.leftenvs[j + 1] = self.be.transfer_left(self.opp[j], self.leftenvs[j], al, al)
                 self.ldeps[j] = al
                 self.n_transfers += 1
         return self.leftenvs[ind]

@@ -45,7 +45,10 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         # fixed budget within one Krylov cycle: nothing is decided per step, so the whole recurrence is enqueued
         # without host synchronisation and the projected matrix is read back once (the per-step sync left the GPU
         # idle ~10 % of a site update at D = 1024)
-        m = fixed_matvecs
+        # a Krylov space cannot be larger than the vector space: beyond x0.size steps the (rounding-level) residual
+        # would be renormalised into a noise direction and pollute the projected matrix (chain-edge sites of a
+        # benchmark sweep have dimension 4 < 8)
+        m = max(1, min(fixed_matvecs, x0.size))
         stride = 2 * m + 1
         slot = ws.get((m * stride,), 1)[0]
         nrm = be.norm(start)
@@ -63,6 +66,13 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
             blk = co[k * stride:k * stride + 2 * kk + 1]
             Hm[:kk, k] = blk[:kk] + blk[kk:2 * kk]
             Hm[kk, k] = np.sqrt(max(blk[2 * kk], 0.0))
+        # invariant subspace reached before the budget ran out (beta_k at rounding level): the later columns were
+        # built from a renormalised rounding residual -> project on the exact part only
+        scale = max(np.abs(Hm[:m, :m]).max(), 1e-300)
+        for k in range(m):
+            if Hm[k + 1, k] <= 1e-13 * scale:
+                m = k + 1
+                break
         Hk = Hm[:m, :m]
         ev, S = np.linalg.eigh((Hk + Hk.T) / 2)
         lam, sv = ev[0], S[:, 0]
@@ -70,7 +80,7 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         be.lincomb(V[:m], sv, out=ritz)
         out = be.empty(*shape)
         be.axpby(1.0 / be.norm(ritz), ritz, 0.0, out)
-        return lam, out, m, res
+        return lam, out, fixed_matvecs, res
     for _restart in range(maxiter):
         nrm = be.norm(start)
         be.axpby(1.0 / nrm, start, 0.0, V[0])
@@ -92,7 +102,9 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
             lam, s = ev[0], S[:, 0]
             res = abs(beta * s[-1])
             done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
-            if (fixed_matvecs is None and res < tol) or beta < 1e-300 or done_fixed:
+            # breakdown: the Krylov space is invariant (always the case once k reaches the vector-space dimension)
+            breakdown = beta <= 1e-13 * max(np.abs(Hk).max(), 1e-300) or k >= x0.size
+            if (fixed_matvecs is None and res < tol) or breakdown or done_fixed:
                 conv = True
                 break
         be.lincomb(V[:k], s, out=ritz)
@@ -101,6 +113,8 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
             break
     out = be.empty(*shape)
     nrm = be.norm(ritz)
+    if nrm == 0.0:
+        raise ZeroDivisionError("eigsolve_sr: zero Ritz vector (zero start vector?)")
     be.axpby(1.0 / nrm, ritz, 0.0, out)
     return lam, out, nmv, res
 

@@ -191,27 +191,6 @@ class FiniteMPS:
         self.ALs[i], self.CLs[i + 1] = Q2.reshape(Dl, d, Dr), R2   # what the next AL(i) / CR(i) computes
         return al_old
 
-    def set_AC_with_rightorth(self, i, vec):
-        """Left-moving site update, the mirror of set_AC_with_leftorth: leftorth(old AC[i]) (the galerkin
-        projector, toolbox.jl:20) and rightorth(new AC[i]) (what CR(i-1) / AR(i) compute next, orthoview.jl:52) are
-        both known once the eigensolver returns -> issued TOGETHER (mpsk_qrlq_pair); the state is left exactly as
-        the lazy views would leave it.  Returns the OLD AL[i]."""
-        be = self.be
-        old = self.ACs[i]
-        ok = (self.ALs[i] is None and old is not None and hasattr(be, "qrlq_pair") and i > 0
-              and self.ALs[i - 1] is not None and vec.shape == old.shape and old.shape[0] == old.shape[2])
-        if not ok:
-            al_old = self.AL(i)
-            self.set_AC(i, vec)
-            return al_old
-        Dl, d, Dr = old.shape
-        Q1, R1, L2, Q2 = be.qrlq_pair(old.reshape(Dl * d, Dr), vec.reshape(Dl, d * Dr))
-        al_old = Q1.reshape(Dl, d, Dr)
-        self.ALs[i], self.CLs[i + 1] = al_old, R1               # what AL(i) would have cached
-        self.set_AC(i, vec)                                      # invalidates, stores ACs[i] = vec
-        self.CLs[i], self.ARs[i] = L2, Q2.reshape(Dl, d, Dr)     # what CR(i-1) computes next (ALs[i-1] is set)
-        return al_old
-
     def norm(self):  # finitemps.jl:467
         n = self.be.norm(self.AC(0))
         return n / np.sqrt(2.0) if self.cplx else n

@@ -414,8 +414,9 @@ def rightorth(A):
 
 
 def tsvd(theta, truncdim=None, truncerr=None):
-    """theta[a,s1,b,s2] -> U[a,s1,k], S[k], Vh[k,b,s2] (dmrg.jl:96).  truncerr: relative 2-norm
-    of discarded weight (TensorKit truncerr semantics, p = 2)."""
+    """theta[a,s1,b,s2] -> U[a,s1,k], S[k], Vh[k,b,s2] (dmrg.jl:96).  truncerr(eps): drop the tail while the
+    2-norm of the discarded values stays <= eps, an ABSOLUTE bound (TensorKit 0.12 `truncerr`, p = 2 -- restated from
+    the published TensorKit source, which is not vendored in the reference tree: parity unpinned)."""
     Dl, d1, Dr, d2 = theta.shape
     M = np.transpose(theta, (0, 1, 3, 2)).reshape(Dl * d1, d2 * Dr)  # cols (s2, b)
     U, S, Vh = np.linalg.svd(M, full_matrices=False)
@@ -423,8 +424,7 @@ def tsvd(theta, truncdim=None, truncerr=None):
     if truncdim is not None:
         k = min(k, truncdim)
     if truncerr is not None:
-        tot = np.linalg.norm(S)
-        while k > 1 and np.linalg.norm(S[k - 1:]) <= truncerr * tot:
+        while k > 1 and np.linalg.norm(S[k - 1:]) <= truncerr:
             k -= 1
     err = np.linalg.norm(S[k:])
     U, S, Vh = U[:, :k], S[:k], Vh[:k]
@@ -466,7 +466,10 @@ def eigsolve_sr(matvec, x0, tol=1e-12, krylovdim=30, maxiter=100, fixed_matvecs=
             lam, s = ev[0], S[:, 0]
             res = abs(beta * s[-1])
             done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
-            if (fixed_matvecs is None and res < tol) or beta < 1e-300 or done_fixed:
+            # Krylov breakdown (invariant subspace; certain once k reaches the vector-space dimension): stop instead
+            # of renormalising a rounding-level residual into the basis
+            breakdown = beta <= 1e-13 * max(np.abs(Hk).max(), 1e-300) or k >= v.size
+            if (fixed_matvecs is None and res < tol) or breakdown or done_fixed:
                 conv = True
                 break
             V.append(w / beta)
@@ -1041,8 +1044,7 @@ def changebonds_svdcut(psi, truncdim=None, truncerr=None):
         if truncdim is not None:
             k = min(k, truncdim)
         if truncerr is not None:
-            tot = np.linalg.norm(S)
-            while k > 1 and np.linalg.norm(S[k - 1:]) <= truncerr * tot:
+            while k > 1 and np.linalg.norm(S[k - 1:]) <= truncerr:
                 k -= 1
         U, S, Vh = U[:, :k], S[:k], Vh[:k]
         al = np.einsum("asb,bk->ask", psi.AL(i), U)

@@ -113,6 +113,19 @@ class CpuBackend:
         o = self.empty(GL.shape[1], x.shape[1], x.shape[2]) if out is None else out
         return self._set(o, y)
 
+    def dAC_blocked(self, H, GLrows, GR, xb, nblk, out=None):
+        """x in nblk row blocks (dist.to_blocked) -> un-block on the host, then the plain dAC on the local rows."""
+        self._count("dAC_blocked")
+        Dl, d, Dr = xb.shape
+        n = Dl // nblk
+        flat = xb.buf[: xb.size].numpy()
+        x = np.concatenate([flat[q * n * d * Dr:(q + 1) * n * d * Dr].reshape((n, d, Dr), order="F") for q in range(nblk)], axis=0)
+        y = mo.dAC(x, H.oracle, self._env(GLrows, H.chil), self._env(GR, H.chir))
+        if y is None:
+            y = np.zeros((GLrows.shape[1], d, Dr))
+        o = self.empty(GLrows.shape[1], d, Dr) if out is None else out
+        return self._set(o, y)
+
     def dAC2(self, H1, H2, GL, GR, x2, out=None):
         self._count("dAC2")
         y = mo.dAC2(self.download(x2), H1.oracle, H2.oracle, self._env(GL, H1.chil), self._env(GR, H2.chir))

@@ -297,12 +297,14 @@ def test_tsvd_truncation_and_small_singular_values(be):
     assert abs(disc - np.linalg.norm(s[40:])) < 1e-14
     U, Vh = be.download(U)[:, :kept], be.download(Vh)[:kept]
     assert relerr((U * S[:kept]) @ Vh, (Uo[:, :40] * s[:40]) @ Vo[:, :40].T) < 1e-12
-    # truncerr (TensorKit semantics: discarded 2-norm <= eps * total 2-norm), cf. oracle tsvd
+    # truncerr (TensorKit 0.12 semantics: discarded 2-norm <= eps, ABSOLUTE), cf. oracle tsvd; pinned on an
+    # UNNORMALISED theta (|theta| = 3.7 |A|), where the absolute and the relative rule keep different numbers of values
     eps = 1e-6
-    _, S2, _, kept2, disc2 = be.tsvd(be.upload(A), trunc_err=eps)
-    _, So, _, erro = mo.tsvd(A.reshape(m, 1, n, 1), truncerr=eps)
-    assert kept2 == len(So)
-    assert abs(disc2 - erro) < 1e-13
+    for scale in (1.0, 3.7e3):
+        _, S2, _, kept2, disc2 = be.tsvd(be.upload(scale * A), trunc_err=eps)
+        _, So, _, erro = mo.tsvd((scale * A).reshape(m, 1, n, 1), truncerr=eps)
+        assert kept2 == len(So) == int(np.sum(np.sqrt(np.cumsum((scale * s[::-1]) ** 2))[::-1] > eps))
+        assert abs(disc2 - erro) < 1e-13 * scale
 
 
 @pytest.mark.parametrize("m,n", [(100, 37), (37, 100), (300, 300), (640, 256), (256, 640)])
@@ -445,6 +447,23 @@ def test_tsplit(be, m, n, k):
     assert np.abs(al @ c @ ar - best).max() < 1e-12
     assert np.abs(np.linalg.svd(c, compute_uv=False) - s[:kk]).max() < 1e-13
     assert np.abs(np.tril(c, -1)).max() < 1e-13 or np.abs(np.triu(c, 1)).max() < 1e-13
+
+
+@pytest.mark.parametrize("m,n", [(48, 40), (40, 48), (64, 64)])
+def test_tsplit_small_rank_deficient_keeps_isometries(be, m, n):
+    """min(m, n) <= 64 goes through mpsk_tsvd: with a rank-deficient theta and max_keep > rank the kept singular values
+    include exact zeros, whose one-sided-Jacobi vectors are zero columns; the split must still return isometries
+    (LAPACK's tsvd! gives an orthonormal completion; the lazy-gauge FiniteMPS and FinEnv assume AL^T AL = I)."""
+    rng = np.random.default_rng(m * n)
+    r, keep = 10, 24
+    A = rng.standard_normal((m, r)) @ rng.standard_normal((r, n))
+    al, c, ar, S, disc = be.tsplit(be.upload(A), max_keep=keep)
+    al, c, ar = be.download(al), be.download(c), be.download(ar)
+    assert al.shape == (m, keep) and ar.shape == (keep, n)
+    assert np.abs(S[r:]).max() < 1e-12 * S[0]
+    assert np.abs(al.T @ al - np.eye(keep)).max() < 1e-12
+    assert np.abs(ar @ ar.T - np.eye(keep)).max() < 1e-12
+    assert np.abs(al @ c @ ar - A).max() < 1e-11 * np.abs(A).max()
 
 
 def test_bond_matrix_inverse_on_device(be):

@@ -1,0 +1,152 @@
+"""HIP path vs the committed ORACLE fixtures at BASELINE-config sizes (tests/golden/make_sweep_traces.py):
+
+  * sweep_traces.json: DMRG / DMRG2 from seeded initial states, compared SWEEP BY SWEEP (energy <= 1e-10 relative, the
+    north-star bar) and on the final middle-bond Schmidt spectrum -- config 1 (TFI L=16 D=4) at its stated size, config 2
+    (Heisenberg S=1) at L=100 D=64 and L=20 D=256, config 4 (Hubbard DMRG2 + tsvd truncation) at L=12 D=128, the
+    headline model (Heisenberg S=1/2) at L=40 D=128;
+  * projected_D1024.npz: dAC / dC / dAC2 / transfer_left / transfer_right at D = 1024 (north-star point and the
+    config-4 shape) against 64 random projections + 512 samples of the oracle's output, computed once in the container
+    (a live 1024^3 oracle run per test would take minutes on the GPU box's host).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLD)
+import make_sweep_traces as gen  # noqa: E402
+
+ETOL = 1e-10
+
+
+def _traces():
+    with open(os.path.join(GOLD, "sweep_traces.json")) as f:
+        return json.load(f)
+
+
+def _hamiltonian(mk, be, model, args):
+    return {"tfi": mk.transverse_field_ising, "heis": mk.heisenberg_XXX, "hubbard": mk.hubbard}[model](*args, be=be)
+
+
+@pytest.mark.parametrize("case", sorted(gen.SWEEP_CASES))
+def test_sweep_trace_matches_oracle_fixture(be, case):
+    import mpskit_jl_amd as mk
+    fx = _traces()[case]
+    c = gen.SWEEP_CASES[case]
+    H = _hamiltonian(mk, be, c["model"], c["args"])
+    psi = mk.FiniteMPS(gen.initial_tensors(case), normalize=True, be=be)
+    got = []
+
+    def record(it, p, Hh, envs):
+        got.append((it, float(np.sum(mk.expectation_value(p, Hh, envs)))))
+        return p, envs
+
+    nsw = len(fx["trace"])
+    if c["alg"] == "dmrg":
+        alg = mk.DMRG(tol=1e-12, maxiter=nsw, finalize=record)
+    else:
+        alg = mk.DMRG2(tol=1e-12, maxiter=nsw, trunc_dim=c["D"], finalize=record)
+    p, envs, eps = mk.find_groundstate(psi, H, alg)
+    assert len(got) == nsw
+    for (it, E), (it_o, E_o, eps_o) in zip(got, fx["trace"]):
+        assert it == it_o
+        assert abs(E - E_o) <= ETOL * abs(E_o), (case, it, E, E_o)
+    # convergence measure of the last sweep: same order of magnitude (it is a max over sites of a quantity that is
+    # itself at the solver tolerance once converged)
+    eps_o = fx["trace"][-1][2]
+    assert eps <= max(3 * eps_o, 1e-11), (eps, eps_o)
+    # final Schmidt spectrum of the middle bond (singular values of CR)
+    cr = be.download(p.CR(fx["mid_bond"]))
+    s = np.linalg.svd(cr, compute_uv=False)
+    so = np.array(fx["schmidt"])
+    assert len(s) == len(so)
+    assert np.abs(s - so).max() <= 1e-8, np.abs(s - so).max()
+    if "exact_ground_energy" in fx:
+        assert got[-1][1] >= fx["exact_ground_energy"] - 1e-10
+
+
+def _slabs_to_colmajor(be, t):
+    """device env (W, Db, Dk) -> host [Db, Dk, W] (the layout the fixture reduced)."""
+    W, Db, Dk = t.shape
+    flat = t.buf[: t.size].cpu().numpy()
+    return np.transpose(flat.reshape(W, Dk, Db), (2, 1, 0))
+
+
+@pytest.mark.parametrize("case", sorted(gen.PROJ_CASES))
+def test_operators_D1024_against_projected_oracle_outputs(be, case):
+    import mpskit_jl_amd as mk
+    import mpskit_oracle as mo
+    fx = np.load(os.path.join(GOLD, "projected_D1024.npz"))
+    c = gen.PROJ_CASES[case]
+    Ho = gen.proj_hamiltonian(mo, case)[0]            # host block table only (no oracle arithmetic here)
+    if c["model"] == "tfi2":
+        X = np.array([[0.0, 1], [1, 0]]); Z = np.array([[1.0, 0], [0, -1]]); E = np.eye(2)
+        g = c["args"][0]
+        Hg = mk.from_twosite(-(np.kron(Z, Z) + (g / 2) * (np.kron(X, E) + np.kron(E, X))).reshape(2, 2, 2, 2), be=be)[0]
+    else:
+        Hg = _hamiltonian(mk, be, c["model"], c["args"])[0]
+    assert list(Hg.chil) == list(Ho.chil)
+    inp = gen.projected_inputs(case, Ho.chil)
+    GL, GR = be.upload_env(inp["GL"]), be.upload_env(inp["GR"])
+    for op in c["ops"]:
+        if op == "dAC":
+            y = be.download(be.dAC(Hg, GL, GR, be.upload(inp["x"])))
+        elif op == "dC":
+            y = be.download(be.dC(GL, GR, be.upload(inp["c"])))
+        elif op == "dAC2":
+            y = be.download(be.dAC2(Hg, Hg, GL, GR, be.upload(inp["x2"])))
+        elif op == "tl":
+            y = _slabs_to_colmajor(be, be.transfer_left(Hg, GL, be.upload(inp["A"]), be.upload(inp["Ab"])))
+        elif op == "tr":
+            y = _slabs_to_colmajor(be, be.transfer_right(Hg, GR, be.upload(inp["A"]), be.upload(inp["Ab"])))
+        proj, samp, nrm = gen.reduce_output(case, op, y)
+        ref_nrm = float(fx[f"{case}.{op}.norm"])
+        n = y.size
+        # a projection of an error vector e on a uniform[-0.5, 0.5) vector has standard deviation |e| / sqrt(12):
+        # |e| <= 1e-13 |y| is asserted through 64 of them (and the norm, and 512 element samples)
+        assert abs(nrm - ref_nrm) <= 1e-12 * ref_nrm, (case, op)
+        dproj = np.abs(proj - fx[f"{case}.{op}.proj"]).max()
+        dsamp = np.abs(samp - fx[f"{case}.{op}.samp"]).max()
+        print(f"{case}.{op}: |dproj|/|y| = {dproj / ref_nrm:.2e}  |dsamp|/rms = {dsamp / (ref_nrm / np.sqrt(n)):.2e}")
+        assert dproj <= 3e-13 * ref_nrm, (case, op, dproj / ref_nrm)
+        assert dsamp <= 1e-11 * ref_nrm / np.sqrt(n), (case, op)
+
+
+def test_calc_galerkin_value_parity(be):
+    """toolbox.jl:17-25: the VALUE of calc_galerkin on the same (unconverged) state equals the oracle's on every site,
+    in both gauge positions, and the sweep's `first_image` shortcut (the eigensolver's first matvec reused as H_AC AC)
+    returns the same number as the plain evaluation."""
+    import mpskit_jl_amd as mk
+    import mpskit_oracle as mo
+    from mpskit_jl_amd import algorithms as alg, krylov
+    from mpskit_jl_amd.derivatives import ddAC
+    rng = np.random.default_rng(31)
+    L, d, D = 10, 2, 24
+    dims = gen.bond_dims(L, d, D)
+    As = [rng.random((dims[i], d, dims[i + 1])) for i in range(L)]
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)
+    pg, po = mk.FiniteMPS(As, normalize=True, be=be), mo.FiniteMPS(As, normalize=True)
+    eg, eo = mk.environments(pg, Hg), mo.FinEnv(po, Ho)
+    for pos in list(range(L)) + [4, 1]:
+        vg, vo = mk.calc_galerkin(pg, pos, eg), mo.calc_galerkin(po, pos, eo)
+        assert abs(vg - vo) <= 1e-12 * max(vo, 1e-3), (pos, vg, vo)
+    # first_image path == plain path (one eigensolve, then both evaluations on the OLD tensor)
+    pos = 5
+    h = ddAC(pos, pg, Hg, eg)
+    ac_old, al_old = pg.AC(pos), pg.AL(pos)
+    g = be.empty(*ac_old.shape)
+    krylov.eigsolve_sr(be, h, ac_old, tol=1e-10, krylovdim=10, first_image=g)
+    v_first = alg._galerkin(be, h, ac_old, al_old, g)
+    v_plain = alg._galerkin(be, h, ac_old, al_old, None)
+    v_or = mo.calc_galerkin(po, pos, eo)
+    assert abs(v_first - v_plain) <= 1e-13 and abs(v_plain - v_or) <= 1e-12
+    # and after a few sweeps (nearly converged state: the value is small, compare absolutely)
+    pg2, eg2, _ = mk.find_groundstate(pg, Hg, mk.DMRG(tol=1e-6, maxiter=2))
+    po2, eo2, _, _ = mo.dmrg(po, Ho, tol=1e-6, maxiter=2)
+    for pos in (2, 5, 8):
+        vg, vo = mk.calc_galerkin(pg2, pos, eg2), mo.calc_galerkin(po2, pos, eo2)
+        assert abs(vg - vo) <= 1e-9, (pos, vg, vo)

@@ -83,6 +83,27 @@ def test_krylov_eigsolve_matches_dense(cb):
     assert abs(lamP - np.max(np.abs(np.linalg.eigvals(P)))) < 1e-9
 
 
+@pytest.mark.parametrize("n", [1, 2, 4, 6])
+@pytest.mark.parametrize("sync_free", [True, False])
+def test_krylov_fixed_budget_larger_than_space(cb, n, sync_free):
+    """A fixed matvec budget larger than the vector-space dimension (chain-edge sites of the benchmark sweep: 4 < 8)
+    must stop at the Krylov breakdown instead of renormalising a rounding-level residual into the basis: the Ritz
+    value is never below the spectrum and the returned vector is the eigenvector (product AND oracle)."""
+    rng = np.random.default_rng(10 + n)
+    M = rng.standard_normal((n, n))
+    M = M + M.T
+    w, U = np.linalg.eigh(M)
+    x0 = rng.random(n)
+    mv = lambda x, out: cb._set(out, M @ cb.download(x))
+    kd = 8 if sync_free else 5       # fixed_matvecs <= krylovdim takes the sync-free recurrence, otherwise the host loop
+    lam, vec, _, _ = krylov.eigsolve_sr(cb, mv, cb.upload(x0), fixed_matvecs=8, krylovdim=kd)
+    v = cb.download(vec)
+    assert lam >= w[0] - 1e-12 and abs(lam - w[0]) < 1e-10
+    assert abs(v @ M @ v - w[0]) < 1e-10 and abs(abs(v @ U[:, 0]) - 1) < 1e-9
+    lo, vo, _ = mo.eigsolve_sr(lambda x: M @ x, x0, fixed_matvecs=8, krylovdim=kd)
+    assert abs(lo - w[0]) < 1e-10 and abs(abs(vo @ U[:, 0]) - 1) < 1e-9
+
+
 @pytest.mark.parametrize("model", ["heis", "tfi"])
 def test_dmrg_driver_matches_oracle(cb, model):
     """dmrg.jl:22-55 on the product's host code == the oracle's restatement (energies to 1e-10)."""
@@ -439,3 +460,10 @@ def test_two_site_drivers_host_logic(cb):
     psi2, envs2 = mk.timestep(psi, Hg, 0.0, -0.1j, mk.TDVP2(trunc_dim=8), envs)
     e_after = float(np.sum(mk.expectation_value(psi2, Hg, envs2)))        # expectation_value divides by <psi|psi>
     assert e_after < e_before - 1e-3
+
+
+def test_calc_galerkin_value_parity_host(cb):
+    """toolbox.jl:17-25 through the product's host code on the stand-in backend (the GPU twin is
+    tests/test_gpu_traces.py::test_calc_galerkin_value_parity, same body)."""
+    from test_gpu_traces import test_calc_galerkin_value_parity as body
+    body(cb)

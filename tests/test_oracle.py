@@ -138,8 +138,12 @@ def test_tsvd_truncation_semantics():
     assert len(S) == 5
     full = np.linalg.svd(np.transpose(th, (0, 1, 3, 2)).reshape(12, 14), compute_uv=False)
     assert np.allclose(S, full[:5]) and abs(err - np.linalg.norm(full[5:])) < 1e-13
-    U, S, Vh, err = mo.tsvd(th, truncerr=0.2)
-    assert np.linalg.norm(full[len(S):]) <= 0.2 * np.linalg.norm(full) < np.linalg.norm(full[len(S) - 1:]) + 1e-15
+    # truncerr(eps): ABSOLUTE bound on the discarded 2-norm (TensorKit 0.12; parity unpinned, see oracle tsvd)
+    eps = 0.2 * np.linalg.norm(full)
+    U, S, Vh, err = mo.tsvd(th, truncerr=eps)
+    assert np.linalg.norm(full[len(S):]) <= eps < np.linalg.norm(full[len(S) - 1:]) + 1e-15
+    U2, S2, _, _ = mo.tsvd(3.0 * th, truncerr=eps)          # not scale invariant: an unnormalised theta keeps more
+    assert len(S2) > len(S)
 
 
 def test_golden_vectors_regression():

@@ -1,6 +1,7 @@
 """Rank process of tests/test_gpu_dist.py: world_size ranks share GPU 0, collectives staged through the host (gloo).
-Checks the device-side sharding plumbing (row blocks, local mpsk_dAC with Dlo = D / P, re-interleave) and a sharded
-DMRG sweep against the unsharded result.  usage: dist_gpu_check.py RANK WORLD PORT"""
+Checks the device side of the bond-sharded sweep (mpsk_dAC_blocked on the local rows, in-place gather into the blocked
+vector, storage-sharded environments and their updates) against the unsharded result.
+usage: dist_gpu_check.py RANK WORLD PORT"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
@@ -11,38 +12,43 @@ from mpskit_jl_amd import dist as md, algorithms as alg, krylov
 
 dist.init_process_group("gloo", rank=rank, world_size=world)
 be = mk.Backend(0)
-pl = md.HostStagedPlumbing(be)
+comm = md.Comm(world, rank, staged=True)
 rng = np.random.default_rng(5)                       # same inputs on every rank
 D, d, W = 192, 2, 5
 H = mk.heisenberg_XXX(0.5, be=be)
 GL, GR = be.upload_env([rng.standard_normal((D, 1, D)) for _ in range(W)]), be.upload_env([rng.standard_normal((D, 1, D)) for _ in range(W)])
 x = be.upload(rng.standard_normal((D, d, D)))
 ref = be.download(be.dAC(H[1], GL, GR, x))
-y = be.download(md.ShardedMatvec(pl, H[1], GL, GR, world, rank)(x))
+n = D // world
+op = md.ShardedSiteOp(be, comm, H[1], md.rows_of_env(be, GL, rank * n, (rank + 1) * n), GR)
+y = be.download(op.decode(op(op.encode(x))))
 err = np.abs(y - ref).max() / np.abs(ref).max()
-# sharded sweep == unsharded sweep (bit-identical collectives: every rank must hold the same state)
+# sharded sweep (storage-sharded environments) == unsharded sweep; every rank must hold the same state
 L, Dm = 12, 128
 psi = mk.FiniteMPS.random(L, 2, Dm, np.random.default_rng(1), be=be)
 ps = psi.copy()
 eig = mk.Arnoldi(fixed_matvecs=4, krylovdim=4)
-alg.dmrg_sweep(psi, H, mk.FinEnv(psi, H), eig, krylov.KrylovWorkspace(be))
-alg.dmrg_sweep(ps, H, mk.FinEnv(ps, H), eig, krylov.KrylovWorkspace(be), md.shard_wrapper(be, world, rank, None, 32, plumbing=pl))
-# sharded environment updates (all-reduce / all-gather + device re-interleave)
-st = md.ShardedTransfer(pl, world, rank, None, 32)
-A = be.upload(rng.standard_normal((D, d, D)))
-tl_s, tl_u = be.download(st.transfer_left(H[1], GL, A, A)), be.download(be.transfer_left(H[1], GL, A, A))
-tr_s, tr_u = be.download(st.transfer_right(H[1], GR, A, A)), be.download(be.transfer_right(H[1], GR, A, A))
-err_t = max(np.abs(tl_s - tl_u).max() / np.abs(tl_u).max(), np.abs(tr_s - tr_u).max() / np.abs(tr_u).max())
-pt = mk.FiniteMPS.random(L, 2, Dm, np.random.default_rng(1), be=be)
-alg.dmrg_sweep(pt, H, mk.FinEnv(pt, H, transfer_ops=st), eig, krylov.KrylovWorkspace(be), md.shard_wrapper(be, world, rank, None, 32, plumbing=pl))
-e3 = float(np.sum(mk.expectation_value(pt, H, mk.FinEnv(pt, H))))
-e1 = float(np.sum(mk.expectation_value(psi, H, mk.FinEnv(psi, H))))
-e2 = float(np.sum(mk.expectation_value(ps, H, mk.FinEnv(ps, H))))
+eu, es = mk.FinEnv(psi, H), md.ShardedFinEnv(ps, H, comm, min_block=32)
+for _ in range(2):
+    alg.dmrg_sweep(psi, H, eu, eig, krylov.KrylovWorkspace(be))
+    alg.dmrg_sweep(ps, H, es, eig, krylov.KrylovWorkspace(be))
+# environments: gathered shards == the unsharded tensors
+err_t = 0.0
+for pos in (3, 6, 9):
+    for a, b in ((es.leftenv(pos, ps), eu.leftenv(pos, psi)), (es.rightenv(pos, ps), eu.rightenv(pos, psi))):
+        a, b = be.download(a), be.download(b)
+        err_t = max(err_t, np.abs(a - b).max() / np.abs(b).max())
+stored, transient = es.bytes_local()
+full = 8 * (sum(t.size for t in eu.leftenvs if t is not None) + sum(t.size for t in eu.rightenvs if t is not None))
+e1 = float(np.sum(mk.expectation_value(psi, H, eu)))
+e2 = float(np.sum(mk.expectation_value(ps, H, es)))
 t = torch.tensor([e2], dtype=torch.float64)
 lst = [torch.zeros_like(t) for _ in range(world)]
 dist.all_gather(lst, t)
 spread = max(abs(float(a) - e2) for a in lst)
-ok = err < 1e-13 and err_t < 1e-13 and abs(e1 - e2) < 1e-10 * abs(e1) and abs(e1 - e3) < 1e-10 * abs(e1) and spread == 0.0 and st.n_collectives > 2
-print(f"rank {rank}: matvec relerr {err:.2e}, transfer relerr {err_t:.2e}, sharded-env sweep {e3:.12f}, sweep energy {e1:.12f} vs sharded {e2:.12f}, spread {spread:.1e} -> {'OK' if ok else 'FAIL'}", flush=True)
+ok = (err < 1e-13 and err_t < 1e-11 and abs(e1 - e2) < 1e-10 * abs(e1) and spread == 0.0 and comm.n_allreduce > 2
+      and comm.n_allgather > 20 and stored < 0.6 * full and es.n_transfers == eu.n_transfers)
+print(f"rank {rank}: matvec relerr {err:.2e}, env relerr {err_t:.2e}, sweep energy {e1:.12f} vs sharded {e2:.12f}, spread {spread:.1e}, "
+      f"env bytes {stored / full:.2f} of replicated, collectives {comm.n_allgather} ag / {comm.n_allreduce} ar -> {'OK' if ok else 'FAIL'}", flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
