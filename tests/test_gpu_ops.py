@@ -343,14 +343,17 @@ def test_tsvd_graded_and_rank_deficient_preconditioned(be):
     U, Vh = be.download(U)[:, :kept], be.download(Vh)[:kept]
     assert np.abs(U.T @ U - np.eye(kept)).max() < 1e-12 and np.abs(Vh @ Vh.T - np.eye(kept)).max() < 1e-12
     assert relerr((U * S[:kept]) @ Vh, (Uo[:, :128] * s[:128]) @ Vo[:, :128].T) < 1e-12
+    from mpskit_jl_amd._lib import MpskError
     try:
         be.set_svd_mode(False)
-        _, S0, _, _, _ = be.tsvd(be.upload(A), max_keep=128)
+        # plain block Jacobi stalls on graded input: after the 40-sweep cap the factors would not be isometries, and the
+        # library says so instead of returning them (mpsk.h: "did not converge")
+        with pytest.raises(MpskError, match="did not converge"):
+            be.tsvd(be.upload(A), max_keep=128)
         sw_plain = be.svd_sweeps()
-        assert np.abs(be.download(S0)[:n] - s).max() < 1e-12   # plain block Jacobi stalls on graded input (sweep cap)
     finally:
         be.set_svd_mode(True)
-    assert sw_pre <= 12 and sw_pre < sw_plain, (sw_pre, sw_plain)
+    assert sw_pre <= 12 and sw_pre < sw_plain == 40, (sw_pre, sw_plain)
     # exact rank deficiency: rank 100 of 256
     B = rng.standard_normal((384, 100)) @ rng.standard_normal((100, 256))
     U, S, Vh, kept, disc = be.tsvd(be.upload(B))

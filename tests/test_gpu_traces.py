@@ -107,13 +107,13 @@ def test_operators_D1024_against_projected_oracle_outputs(be, case):
         ref_nrm = float(fx[f"{case}.{op}.norm"])
         n = y.size
         # a projection of an error vector e on a uniform[-0.5, 0.5) vector has standard deviation |e| / sqrt(12):
-        # |e| <= 1e-13 |y| is asserted through 64 of them (and the norm, and 512 element samples)
+        # measured on MI355X: |dproj| <= 1e-14 |y|, samples within 2e-14 of the rms element (profiles/r02_pytest_gpu.log)
         assert abs(nrm - ref_nrm) <= 1e-12 * ref_nrm, (case, op)
         dproj = np.abs(proj - fx[f"{case}.{op}.proj"]).max()
         dsamp = np.abs(samp - fx[f"{case}.{op}.samp"]).max()
         print(f"{case}.{op}: |dproj|/|y| = {dproj / ref_nrm:.2e}  |dsamp|/rms = {dsamp / (ref_nrm / np.sqrt(n)):.2e}")
-        assert dproj <= 3e-13 * ref_nrm, (case, op, dproj / ref_nrm)
-        assert dsamp <= 1e-11 * ref_nrm / np.sqrt(n), (case, op)
+        assert dproj <= 5e-14 * ref_nrm, (case, op, dproj / ref_nrm)
+        assert dsamp <= 2e-13 * ref_nrm / np.sqrt(n), (case, op)
 
 
 def test_calc_galerkin_value_parity(be):
