@@ -181,13 +181,14 @@ def main():
         GR = mk.DTensor(torch.rand(W * D * D, dtype=torch.float64, device=be.device), (W, D, D))
         x = mk.DTensor(torch.rand(D * d * D, dtype=torch.float64, device=be.device), (D, d, D))
         y = be.empty(D, d, D)
+        hop = mk.MPO_ddAC(be, H[0], GL, GR)         # what the sweep applies: prepared once per site, then applied
         for _ in range(3):
-            be.dAC(H[0], GL, GR, x, out=y)
+            hop(x, out=y)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         nrep = 20
         e0.record()
         for _ in range(nrep):
-            be.dAC(H[0], GL, GR, x, out=y)
+            hop(x, out=y)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / nrep

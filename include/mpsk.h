@@ -113,6 +113,19 @@ int mpsk_dAC(mpsk_ctx* ctx, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, con
  * it INTO the blocked destination vector and all-gathers in place).  nblk == 1 is mpsk_dAC. */
 int mpsk_dAC_blocked(mpsk_ctx* ctx, const mpsk_mposlice* H, int nblk, int Dlo, int Dl, int Dr, const void* GL,
                      const void* GR, const void* xblk, void* y);
+/* Prepared effective Hamiltonian == the reference's MPO_ddAC object (derivatives.jl:11-15, 44-46): `ddAC(pos, psi, H, envs)`
+ * builds it ONCE per site visit from (H[pos], leftenv, rightenv) and the Krylov solver applies it many times.
+ * mpsk_hac_create folds the MPO tensor into the right environment (GRc[(w,s,t)] = sum_v O[w,t,s,v] GR[v], one
+ * elementwise pass) whenever that does not cost extra GEMM work (Heisenberg / TFI-type MPOs): the application is then
+ * TWO GEMM launches with no slab mix and one intermediate instead of two; otherwise it applies exactly what mpsk_dAC
+ * does.  GL / GR must stay valid and unchanged while the object lives.  x may be in the blocked layout (nblk row
+ * blocks, see mpsk_dAC_blocked; nblk = 1: plain).  mpsk_hac_info: mode 1 = combined environment (nslabs of them). */
+typedef struct mpsk_hac mpsk_hac;
+int mpsk_hac_create(mpsk_ctx* ctx, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
+                    mpsk_hac** out);
+int mpsk_hac_apply(mpsk_hac* h, const void* x, int nblk, void* y);
+int mpsk_hac_destroy(mpsk_hac* h);
+int mpsk_hac_info(const mpsk_hac* h, int* mode, int* nslabs);
 /* mpsk_dC == dC(x, leftenv::Vector, rightenv::Vector)   derivatives.jl:171-193
  *   y[p,q] = sum_w GL[w][p,a] c[a,b] GR[w][b,q] */
 int mpsk_dC(mpsk_ctx* ctx, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR,

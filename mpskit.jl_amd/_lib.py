@@ -53,6 +53,10 @@ SIGNATURES = {
                          C.c_void_p, C.c_void_p],
     "mpsk_ctx_get_stream": [C.c_void_p, c_void_pp],
     "mpsk_ctx_get_device": [C.c_void_p, C.POINTER(C.c_int)],
+    "mpsk_hac_create": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_void_pp],
+    "mpsk_hac_apply": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    "mpsk_hac_destroy": [C.c_void_p],
+    "mpsk_hac_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mpsk_dC": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                 C.c_void_p],
     "mpsk_dAC2": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -189,6 +189,11 @@ class Backend:
               "mpsk_dAC_blocked")
         return y
 
+    def hac_create(self, H, GL: DTensor, GR: DTensor):
+        """mpsk_hac_create: the prepared effective Hamiltonian of one site (MPO_ddAC).  Returns a PreparedHAC that
+        keeps GL / GR alive and releases the device-side object when it is garbage collected."""
+        return PreparedHAC(self, H, GL, GR)
+
     def dC(self, GL: DTensor, GR: DTensor, c: DTensor, out: DTensor = None):
         Dl, Dr = c.shape
         W, Dlo, _ = GL.shape
@@ -383,6 +388,42 @@ class Backend:
         cf = (C.c_double * len(xs))(*[float(c) for c in coefs])
         check(self.lib.mpsk_vlincomb(self.ctx, y.size, len(xs), self._ptrs(xs), cf, y.ptr), "mpsk_vlincomb")
         return y
+
+
+class PreparedHAC:
+    """Owner of an mpsk_hac handle (include/mpsk.h): `apply(x, out, nblk)` is one matvec."""
+
+    def __init__(self, be: Backend, H, GL: DTensor, GR: DTensor):
+        Wl, Dlo, Dl = GL.shape
+        Wr, Dr, Dr2 = GR.shape
+        assert Wl == H.Wl and Wr == H.Wr and Dr == Dr2, (GL.shape, GR.shape)
+        self.be, self.H, self.GL, self.GR = be, H, GL, GR           # references keep the operands alive
+        self.Dlo, self.Dl, self.Dr, self.d = Dlo, Dl, Dr, H.d
+        h = C.c_void_p()
+        check(be.lib.mpsk_hac_create(be.ctx, H.handle, Dlo, Dl, Dr, GL.ptr, GR.ptr, C.byref(h)), "mpsk_hac_create")
+        self.handle = h
+
+    def info(self):
+        mode, ns = C.c_int(), C.c_int()
+        check(self.be.lib.mpsk_hac_info(self.handle, C.byref(mode), C.byref(ns)), "mpsk_hac_info")
+        return {"mode": mode.value, "combined_slabs": ns.value}
+
+    def apply(self, x: DTensor, out: DTensor = None, nblk=1):
+        assert x.shape == (self.Dl, self.d, self.Dr), (x.shape, (self.Dl, self.d, self.Dr))
+        y = self.be.empty(self.Dlo, self.d, self.Dr) if out is None else out
+        check(self.be.lib.mpsk_hac_apply(self.handle, x.ptr, int(nblk), y.ptr), "mpsk_hac_apply")
+        return y
+
+    def close(self):
+        if getattr(self, "handle", None) and self.be.ctx:
+            self.be.lib.mpsk_hac_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceMPOSlice:

@@ -2,6 +2,7 @@
 // decomposition of every hot-path operator into  MFMA-GEMM -> slab-mix -> MFMA-GEMM  launches.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <map>
@@ -32,8 +33,16 @@ struct mpsk_mposlice {
   MixPlan fwd;                // (w,s) -> (v,t)   in = s + d*w, out = t + d*v
   MixPlan bwd;                // (v,t) -> (w,s)   in = t + d*v, out = s + d*w
   std::vector<char> row_used, col_used;
+  // "right-combined" form of the matvec (mpsk_hac): the MPO tensor is folded into the right environment once per
+  // site visit,  GRc[c] = sum_v O[w_c, t_c, s_c, v] GR[v]  for every (w, s, t) with a non-zero entry, so that
+  //   y[:, t, :] = sum_{c : t_c = t} T1[w_c][:, s_c, :] GRc[c]   needs no slab mix between the two GEMM stages.
+  MixPlan rc;                      // out slab c <- in slab v
+  std::vector<int> rc_w, rc_s, rc_t;
+  int rc_nseg = 0;                 // max over t of the number of c with t_c = t (lists are padded to this length)
   double O(int w, int t, int s, int v) const { return Ofull[w + (size_t)Wl * (t + d * (s + (size_t)d * v))]; }
 };
+
+struct PoolBuf { void* p; size_t bytes; bool used; };
 
 struct mpsk_ctx {
   int device = 0;
@@ -57,6 +66,20 @@ struct mpsk_ctx {
   size_t ws3_bytes = 0;
   int* h_flags = nullptr;       // pinned [2]
   std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
+  std::vector<PoolBuf> pool;    // device buffers of prepared operators (mpsk_hac), reused across site visits
+};
+
+// prepared effective Hamiltonian of one site (MPO_ddAC of derivatives.jl:11-15: built once, applied by every Krylov step)
+struct mpsk_hac {
+  mpsk_ctx* ctx;
+  const mpsk_mposlice* H;
+  int Dlo, Dl, Dr;
+  const double* GL;
+  const double* GR;
+  int mode;                     // 0: GEMM -> slab mix -> GEMM (mpsk_dAC);  1: right-combined environment, no mix
+  double* GRc = nullptr;        // [nc + 1][Dr, Dr]   (last slab: zeros, pads the shorter segment lists)
+  int64_t* zseg = nullptr;      // device [2][d][nseg]: A offsets (into T1), B offsets (into GRc)
+  int pool_idx = -1;
 };
 constexpr int MAXK = 256;
 
@@ -97,6 +120,7 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   gemm_release_stream(c->stream);     // split-K partial-tile workspaces attached to this ctx's streams
   gemm_release_stream(c->stream2);
   for (auto& kv : c->pair_plans) mix_plan_destroy(&kv.second);
+  for (auto& b : c->pool) if (b.p) (void)hipFree(b.p);
   if (c->ws) (void)hipFree(c->ws);
   if (c->d_scal) (void)hipFree(c->d_scal);
   if (c->d_partial) (void)hipFree(c->d_partial);
@@ -262,6 +286,20 @@ int mpsk_mposlice_create(mpsk_ctx* c, int dtype, int odim, const int32_t* chi_l,
         }
   HIPCHK(mix_plan_create(fwd, d * s->Wr, d * s->Wl, &s->fwd));
   HIPCHK(mix_plan_create(bwd, d * s->Wl, d * s->Wr, &s->bwd));
+  {  // right-combined plan
+    std::vector<MixTerm> rc;
+    std::vector<int> per_t(d, 0);
+    for (int t = 0; t < d; ++t)
+      for (int w = 0; w < s->Wl; ++w)
+        for (int si = 0; si < d; ++si) {
+          bool any = false;
+          for (int v = 0; v < s->Wr; ++v)
+            if (s->O(w, t, si, v) != 0.0) { rc.push_back({(int32_t)s->rc_w.size(), v, s->O(w, t, si, v)}); any = true; }
+          if (any) { s->rc_w.push_back(w); s->rc_s.push_back(si); s->rc_t.push_back(t); per_t[t]++; }
+        }
+    for (int t = 0; t < d; ++t) if (per_t[t] > s->rc_nseg) s->rc_nseg = per_t[t];
+    HIPCHK(mix_plan_create(rc, (int)s->rc_w.size(), s->Wr, &s->rc));
+  }
   *out = s;
   return MPSK_OK;
 }
@@ -277,6 +315,7 @@ int mpsk_mposlice_destroy(mpsk_mposlice* s) {
   }
   mix_plan_destroy(&s->fwd);
   mix_plan_destroy(&s->bwd);
+  mix_plan_destroy(&s->rc);
   delete s;
   return MPSK_OK;
 }
@@ -376,6 +415,125 @@ int mpsk_dAC_blocked(mpsk_ctx* c, const mpsk_mposlice* H, int nblk, int Dlo, int
   REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
   REQUIRE(nblk >= 1 && nblk <= MAXSEG && Dl % nblk == 0, "nblk must divide Dl (and be <= 32)");
   return dAC_impl(c, H, Dlo, Dl, Dr, GL, GR, xblk, nblk, y);
+}
+
+// ---- prepared operator ---------------------------------------------------------------------------
+static int pool_take(mpsk_ctx* c, size_t bytes, void** p, int* idx) {
+  int best = -1;
+  for (size_t i = 0; i < c->pool.size(); ++i)
+    if (!c->pool[i].used && c->pool[i].bytes >= bytes && (best < 0 || c->pool[i].bytes < c->pool[best].bytes)) best = (int)i;
+  if (best < 0) {
+    // drop idle buffers that are too small before growing (bond dimensions grow monotonically along a chain)
+    for (auto& b : c->pool)
+      if (!b.used && b.p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) return fail(MPSK_ERR_NOMEM, "prepared-operator buffer hipMalloc failed");
+    int slot = -1;
+    for (size_t i = 0; i < c->pool.size(); ++i) if (!c->pool[i].p) { slot = (int)i; break; }
+    if (slot < 0) { c->pool.push_back({nullptr, 0, false}); slot = (int)c->pool.size() - 1; }
+    c->pool[slot] = {q, bytes, false};
+    best = slot;
+  }
+  c->pool[best].used = true;
+  *p = c->pool[best].p;
+  *idx = best;
+  return MPSK_OK;
+}
+
+int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
+                    mpsk_hac** out) {
+  REQUIRE(c && H && GL && GR && out, "NULL argument");
+  REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  const int d = H->d, Wl = H->Wl, Wr = H->Wr;
+  int wr_used = 0;
+  for (int v = 0; v < Wr; ++v) wr_used += H->col_used[v] ? 1 : 0;
+  // cost model (stage 1 is the same in both forms): stage-3 slab products at ~50 TFLOP/s, plus -- for the mix form --
+  // the slab-mix pass over T1 / T2 (HBM / L3 traffic at ~3 TB/s) and its launch.  Measured on MI355X: the mix costs
+  // 24 us at D = 1024 (Heisenberg), a dependent launch ~6 us including its gap.
+  const double u3 = 2.0 * Dlo * (double)Dr * Dr;
+  const double slab_bytes = 8.0 * Dlo * (double)d * Dr;
+  const double t_mix = (double)wr_used * d * u3 / 50e12 + (Wl + wr_used) * slab_bytes / 3e12 + 6e-6;
+  const double t_rc = (double)H->rc_nseg * d * u3 / 50e12;
+  auto* h = new mpsk_hac();
+  h->ctx = c; h->H = H; h->Dlo = Dlo; h->Dl = Dl; h->Dr = Dr; h->GL = (const double*)GL; h->GR = (const double*)GR;
+  h->mode = (H->rc_nseg > 0 && t_rc <= t_mix) ? 1 : 0;
+  if (const char* ev = getenv("MPSK_HAC_MODE")) h->mode = (ev[0] == '1' && H->rc_nseg > 0) ? 1 : 0;
+  if (h->mode == 1) {
+    const int nc = (int)H->rc_w.size(), ns = H->rc_nseg;
+    const size_t slabR = (size_t)Dr * Dr;
+    const size_t bytes = sizeof(double) * slabR * (nc + 1) + sizeof(int64_t) * 2 * d * ns + 64;
+    void* buf = nullptr;
+    if (int rc = pool_take(c, bytes, &buf, &h->pool_idx)) { delete h; return rc; }
+    h->GRc = (double*)buf;
+    h->zseg = (int64_t*)((char*)buf + ((sizeof(double) * slabR * (nc + 1) + 15) & ~(size_t)15));
+    // GRc[c] = sum_v O[w_c, t_c, s_c, v] GR[v] ; zero pad slab at index nc
+    SlabIndex ix{1 << 30, 1, (int64_t)slabR, 0, 0, (int64_t)Dr};
+    hipError_t e = mix_apply(H->rc, (const double*)GR, ix, h->GRc, ix, Dr, Dr, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->GRc + slabR * nc, 0, sizeof(double) * slabR, c->stream);
+    // segment tables: stage-3 batch z = t;  A offset into T1 (slab w, plane s), B offset into GRc (slab c)
+    const size_t slab1 = (size_t)Dlo * d * Dr;
+    std::vector<int64_t> tab((size_t)2 * d * ns);
+    for (int t = 0; t < d; ++t) {
+      int k = 0;
+      for (int ci = 0; ci < nc; ++ci)
+        if (H->rc_t[ci] == t) {
+          tab[(size_t)t * ns + k] = (int64_t)H->rc_w[ci] * slab1 + (int64_t)H->rc_s[ci] * Dlo;
+          tab[(size_t)(d + t) * ns + k] = (int64_t)ci * slabR;
+          ++k;
+        }
+      for (; k < ns; ++k) { tab[(size_t)t * ns + k] = 0; tab[(size_t)(d + t) * ns + k] = (int64_t)nc * slabR; }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h->zseg, tab.data(), sizeof(int64_t) * tab.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // `tab` is a host temporary
+    if (e != hipSuccess) { c->pool[h->pool_idx].used = false; delete h; return fail(MPSK_ERR_HIP, hipGetErrorString(e)); }
+  }
+  *out = h;
+  return MPSK_OK;
+}
+
+int mpsk_hac_destroy(mpsk_hac* h) {
+  if (!h) return MPSK_OK;
+  if (h->pool_idx >= 0 && h->pool_idx < (int)h->ctx->pool.size()) h->ctx->pool[h->pool_idx].used = false;
+  delete h;
+  return MPSK_OK;
+}
+
+int mpsk_hac_info(const mpsk_hac* h, int* mode, int* nslabs) {
+  REQUIRE(h, "hac is NULL");
+  if (mode) *mode = h->mode;
+  if (nslabs) *nslabs = h->mode == 1 ? (int)h->H->rc_w.size() : 0;
+  return MPSK_OK;
+}
+
+int mpsk_hac_apply(mpsk_hac* h, const void* x, int nblk, void* y) {
+  REQUIRE(h && x && y, "NULL argument");
+  mpsk_ctx* c = h->ctx;
+  const mpsk_mposlice* H = h->H;
+  const int Dlo = h->Dlo, Dl = h->Dl, Dr = h->Dr;
+  REQUIRE(nblk >= 1 && nblk <= MAXSEG && Dl % nblk == 0, "nblk must divide Dl (and be <= 32)");
+  if (h->mode == 0) return dAC_impl(c, H, Dlo, Dl, Dr, h->GL, h->GR, x, nblk, y);
+  HIPCHK(hipSetDevice(c->device));
+  const int d = H->d, Wl = H->Wl, ns = H->rc_nseg;
+  const size_t slab = (size_t)Dlo * d * Dr;
+  if (int rc = ensure_ws(c, sizeof(double) * slab * Wl)) return rc;
+  double* T1 = (double*)c->ws;
+  // stage 1: T1[w] = GL[w] * x     (batched over w; x possibly in row blocks = K segments)
+  const int kb = Dl / nblk;
+  GemmArgs g1 = mk(h->GL, (const double*)x, T1, Dlo, d * Dr, kb, Dlo, kb, Dlo);
+  g1.batch = Wl; g1.bsA = (int64_t)Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.nseg = nblk;
+  for (int q = 0; q < nblk; ++q) { g1.segA[q] = (int64_t)q * kb * Dlo; g1.segB[q] = (int64_t)q * kb * d * Dr; }
+  g1.tag = 1;
+  HIPCHK(gemm_f64(g1, c->stream));
+  // stage 3: y[:, t, :] = sum_{c: t_c = t} T1[w_c][:, s_c, :] GRc[c]      (batch over t, per-batch K-segment tables)
+  GemmArgs g3 = mk(T1, h->GRc, (double*)y, Dlo, Dr, Dr, (int64_t)Dlo * d, Dr, (int64_t)Dlo * d);
+  g3.batch = d; g3.bsA = 0; g3.bsB = 0; g3.bsC = (int64_t)Dlo;
+  g3.nseg = ns; g3.zsegA = h->zseg; g3.zsegB = h->zseg + (size_t)d * ns;
+  g3.tabs_even = (Dlo % 2 == 0) && (Dr % 2 == 0);
+  g3.tag = 1;
+  HIPCHK(gemm_f64(g3, c->stream));
+  return MPSK_OK;
 }
 
 int mpsk_dC(mpsk_ctx* c, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR, const void* cm, void* y) {

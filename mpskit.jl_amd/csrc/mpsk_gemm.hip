@@ -122,9 +122,9 @@ __device__ __forceinline__ double row_rot(double x) {
   return __hiloint2double(hi, lo);
 }
 
-template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false>
 __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double* __restrict__ Ab,
-                                                const double* __restrict__ Bb, int m0, int n0, int ktb, int kte,
+                                                const double* __restrict__ Bb, int z, int m0, int n0, int ktb, int kte,
                                                 d4 (&acc)[BM / 32][BN / 32], double* smem) {
   constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile (2x2 waves)
   constexpr int TM = WTM / 16, TN = WTN / 16; // MFMA tiles per wave
@@ -142,8 +142,14 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
   const int tps = (g.K + BK - 1) / BK;  // k-tiles per segment
   LA la; LB lb;
   int seg = ktb / tps, kt = ktb % tps;
-  la.load(Ab + g.segA[seg], g.lda, m0, kt * BK, g.M, g.K, tid);
-  lb.load(Bb + g.segB[seg], g.ldb, n0, kt * BK, g.N, g.K, tid);
+  // K-segment offsets: from the argument block, or (ZS, compile time: a run-time choice cost the plain kernels 30 %)
+  // per batch from device tables -- uniform scalar loads
+  const int64_t* const zsa = ZS ? g.zsegA + (int64_t)z * g.nseg : nullptr;
+  const int64_t* const zsb = ZS ? g.zsegB + (int64_t)z * g.nseg : nullptr;
+  auto offA = [&](int sg) -> int64_t { if constexpr (ZS) return zsa[sg]; else return g.segA[sg]; };
+  auto offB = [&](int sg) -> int64_t { if constexpr (ZS) return zsb[sg]; else return g.segB[sg]; };
+  la.load(Ab + offA(seg), g.lda, m0, kt * BK, g.M, g.K, tid);
+  lb.load(Bb + offB(seg), g.ldb, n0, kt * BK, g.N, g.K, tid);
   la.store(sA, tid);
   lb.store(sB, tid);
   __syncthreads();
@@ -152,8 +158,8 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
     int kt2 = kt + 1, seg2 = seg;
     if (kt2 == tps) { kt2 = 0; seg2 = seg + 1; }
     if (t + 1 < kte) {
-      la.load(Ab + g.segA[seg2], g.lda, m0, kt2 * BK, g.M, g.K, tid);
-      lb.load(Bb + g.segB[seg2], g.ldb, n0, kt2 * BK, g.N, g.K, tid);
+      la.load(Ab + offA(seg2), g.lda, m0, kt2 * BK, g.M, g.K, tid);
+      lb.load(Bb + offB(seg2), g.ldb, n0, kt2 * BK, g.N, g.K, tid);
     }
     const double* a_s = sA + cur * IA::SIZE;
     const double* b_s = sB + cur * IB::SIZE;
@@ -298,7 +304,7 @@ __device__ __forceinline__ void gemm_store_ws(double alpha, double* __restrict__
         slot[(wm * WTM + i * 16 + fr) + (wn * WTN + j * 16 + fq + 4 * rg) * BM] = alpha * acc[i][j][rg];
 }
 
-template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // XCD-aware tile mapping: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
@@ -323,7 +329,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 #pragma unroll
     for (int j = 0; j < BN / 32; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
   const int nt = ((g.K + BK - 1) / BK) * g.nseg;
-  gemm_accumulate<BM, BN, TA, TB, ALIGNED>(g, Ab, Bb, m0, n0, 0, nt, acc, smem);
+  gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS>(g, Ab, Bb, z, m0, n0, 0, nt, acc, smem);
   gemm_store_c<BM, BN, ALIGNED>(g, Cb, z, m0, n0, acc);
 }
 
@@ -333,7 +339,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 // middle of a tile writes its partial tile to workspace slot i, and gemm_sk_fixup_kernel adds the
 // slots to C in a fixed order (deterministic, no atomics).  This removes the wave-quantisation loss
 // of big tiles (640 tiles of 128x128 on 512 resident workgroups at the north-star point).
-template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false>
 __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
@@ -367,7 +373,7 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-    gemm_accumulate<BM, BN, TA, TB, ALIGNED>(g, Ab, Bb, m0, n0, kt0, kt1, acc, smem);
+    gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS>(g, Ab, Bb, z, m0, n0, kt0, kt1, acc, smem);
     // one epilogue for both destinations (uniform parameters): C tile (kt0 == 0) or workspace slot
     const bool toC = (kt0 == 0);
     double* base = toC ? g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC) + m0 + (int64_t)n0 * g.ldc
@@ -406,6 +412,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_sk_f64_kernel(GemmArgs g) {
 template <int BM, int BN, bool ALIGNED>
 __global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_sk_f64_kernel(GemmArgs g) {
   gemm_sk_body<BM, BN, false, false, ALIGNED>(g);
+}
+// per-batch K-segment tables (stage 3 of the prepared operator, mpsk_hac_apply)
+template <int BM, int BN, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_sk_zs_f64_kernel(GemmArgs g) {
+  gemm_sk_body<BM, BN, false, false, ALIGNED, true>(g);
 }
 
 // C tile += sum of the workspace slots of the shares that start strictly inside this tile's k-range
@@ -447,9 +458,13 @@ template <int BM, int BN, bool ALIGNED>
 __global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_f64_kernel(GemmArgs g) {
   gemm_body<BM, BN, false, false, ALIGNED>(g);
 }
+template <int BM, int BN, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_zs_f64_kernel(GemmArgs g) {
+  gemm_body<BM, BN, false, false, ALIGNED, true>(g);
+}
 
 // ---- event profile of the tagged (matvec) launches ---------------------------------------------
-struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned, sk; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned, sk, zs; };
 // The profile is process-wide (every ctx's tagged launches land in one list); the list is mutex-protected because
 // distinct ctxs may launch from distinct host threads.
 static std::atomic<bool> g_prof_on{false};
@@ -479,8 +494,10 @@ std::string gemm_prof_summary() {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     char key[96];
-    snprintf(key, sizeof(key), "%s<%d,%d,%s>", r.sk ? "dac_gemm_sk_f64_kernel" : "dac_gemm_f64_kernel", r.bm, r.bn,
-             r.aligned ? "true" : "false");
+    snprintf(key, sizeof(key), "%s<%d,%d,%s>",
+             r.sk ? (r.zs ? "dac_gemm_sk_zs_f64_kernel" : "dac_gemm_sk_f64_kernel")
+                  : (r.zs ? "dac_gemm_zs_f64_kernel" : "dac_gemm_f64_kernel"),
+             r.bm, r.bn, r.aligned ? "true" : "false");
     Agg& a = agg[key];
     a.n++; a.ms += ms; a.flops += r.flops;
   }
@@ -497,65 +514,64 @@ std::string gemm_prof_summary() {
   return out;
 }
 
+// one launch (+ its event pair when the profile is on and the launch is tagged)
+template <class K>
+static hipError_t launch_one(K kern, std::atomic<uint64_t>& attr, dim3 grid, size_t smem, const GemmArgs& g, hipStream_t s,
+                             bool prof, ProfRec* r) {
+  if (hipError_t e = ensure_dyn_smem(attr, reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return e;
+  if (prof) {
+    (void)hipEventCreate(&r->e0); (void)hipEventCreate(&r->e1);
+    (void)hipEventRecord(r->e0, s);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, s, g);
+  return hipGetLastError();
+}
+
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
 static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   using LA = TileLoader<BM, TA, ALIGNED>;
   using LB = TileLoader<BN, !TB, ALIGNED>;
   constexpr size_t smem = (2 * LA::Img::SIZE + 2 * LB::Img::SIZE) * sizeof(double);
-  auto kern = gemm_f64_kernel<BM, BN, TA, TB, ALIGNED>;
-  static std::atomic<uint64_t> attr_set{0};
-  if (hipError_t e = ensure_dyn_smem(attr_set, reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return e;
   const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
   dim3 grid(tilesM * tilesN, g.batch, 1);
+  const bool zs = g.zsegA != nullptr;
+  if (zs && !(g.tag == 1 && !TA && !TB && g.zsegB != nullptr)) return hipErrorInvalidValue;   // tables: tagged NN launches only
+  const bool tagged = (g.tag == 1 && !TA && !TB);
+  const bool prof = tagged && g_prof_on.load(std::memory_order_relaxed);
+  ProfRec r;
+  r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 0; r.zs = zs;
+  hipError_t e = hipSuccess;
   if constexpr ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) {
     if (g.sk_units > 0) {   // stream-K launch: equal k-tile shares + fixed-order fixup of split tiles
       const int KT = ((g.K + BK - 1) / BK) * g.nseg;
       const int64_t U = (int64_t)tilesM * tilesN * g.batch * KT;
-      const int nwg = (int)((U + g.sk_units - 1) / g.sk_units);
-      const void* kp = (g.tag == 1 && !TA && !TB) ? reinterpret_cast<const void*>(dac_gemm_sk_f64_kernel<BM, BN, ALIGNED>)
-                                                   : reinterpret_cast<const void*>(gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>);
-      static std::atomic<uint64_t> sattr[2];
-      const int which = (g.tag == 1 && !TA && !TB) ? 1 : 0;
-      if (hipError_t e = ensure_dyn_smem(sattr[which], kp, smem); e != hipSuccess) return e;
-      ProfRec r;
-      const bool prof = g_prof_on.load(std::memory_order_relaxed) && which == 1;
-      if (prof) {
-        r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 1;
-        (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
-        (void)hipEventRecord(r.e0, s);
-      }
-      if (which == 1) {
-        if constexpr (!TA && !TB)
-          hipLaunchKernelGGL((dac_gemm_sk_f64_kernel<BM, BN, ALIGNED>), dim3(nwg), dim3(NTHREADS), smem, s, g);
+      const dim3 sgrid((unsigned)((U + g.sk_units - 1) / g.sk_units));
+      r.sk = 1;
+      static std::atomic<uint64_t> a0{0}, a1{0}, a2{0};
+      if constexpr (!TA && !TB) {
+        if (tagged && zs) e = launch_one(dac_gemm_sk_zs_f64_kernel<BM, BN, ALIGNED>, a2, sgrid, smem, g, s, prof, &r);
+        else if (tagged) e = launch_one(dac_gemm_sk_f64_kernel<BM, BN, ALIGNED>, a1, sgrid, smem, g, s, prof, &r);
+        else e = launch_one(gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>, a0, sgrid, smem, g, s, false, &r);
       } else {
-        hipLaunchKernelGGL((gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>), dim3(nwg), dim3(NTHREADS), smem, s, g);
+        e = launch_one(gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>, a0, sgrid, smem, g, s, false, &r);
       }
+      if (e != hipSuccess) return e;
       hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN>), dim3(tilesM * tilesN * g.batch), dim3(256), 0, s, g);
       // the event window covers the split GEMM AND its fixup launch: the flops credited are those of the whole stage
       if (prof) { (void)hipEventRecord(r.e1, s); prof_push(r); }
       return hipGetLastError();
     }
   }
+  static std::atomic<uint64_t> b0{0}, b1{0}, b2{0};
   if constexpr (!TA && !TB) {
-    if (g.tag == 1) {
-      auto dk = dac_gemm_f64_kernel<BM, BN, ALIGNED>;
-      static std::atomic<uint64_t> dattr{0};
-      if (hipError_t e = ensure_dyn_smem(dattr, reinterpret_cast<const void*>(dk), smem); e != hipSuccess) return e;
-      if (g_prof_on.load(std::memory_order_relaxed)) {
-        ProfRec r;
-        r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 0;
-        (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
-        (void)hipEventRecord(r.e0, s);
-        hipLaunchKernelGGL(dk, grid, dim3(NTHREADS), smem, s, g);
-        (void)hipEventRecord(r.e1, s);
-        prof_push(r);
-      } else {
-        hipLaunchKernelGGL(dk, grid, dim3(NTHREADS), smem, s, g);
-      }
-      return hipGetLastError();
-    }
+    if (tagged && zs) e = launch_one(dac_gemm_zs_f64_kernel<BM, BN, ALIGNED>, b2, grid, smem, g, s, prof, &r);
+    else if (tagged) e = launch_one(dac_gemm_f64_kernel<BM, BN, ALIGNED>, b1, grid, smem, g, s, prof, &r);
+    else e = launch_one(gemm_f64_kernel<BM, BN, TA, TB, ALIGNED>, b0, grid, smem, g, s, false, &r);
+  } else {
+    e = launch_one(gemm_f64_kernel<BM, BN, TA, TB, ALIGNED>, b0, grid, smem, g, s, false, &r);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, s, g);
+  if (e != hipSuccess) return e;
+  if (prof) { (void)hipEventRecord(r.e1, s); prof_push(r); }
   return hipGetLastError();
 }
 
@@ -679,8 +695,10 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   bool aligned = (g.M % bm == 0) && (g.N % bn == 0) && (g.K % BK == 0) && (g.lda % 2 == 0) &&
                  (g.ldb % 2 == 0) && (g.bsA % 2 == 0) && (g.bsB % 2 == 0) &&
                  ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
-  if (g.tabA || g.tabB) aligned = aligned && g.tabs_even;
-  for (int i = 0; i < g.nseg; ++i) aligned = aligned && (g.segA[i] % 2 == 0) && (g.segB[i] % 2 == 0);
+  if (g.tabA || g.tabB || g.zsegA || g.zsegB) aligned = aligned && g.tabs_even;
+  if (!g.zsegA) for (int i = 0; i < g.nseg && i < MAXSEG; ++i) aligned = aligned && (g.segA[i] % 2 == 0);
+  if (!g.zsegB) for (int i = 0; i < g.nseg && i < MAXSEG; ++i) aligned = aligned && (g.segB[i] % 2 == 0);
+  if ((!g.zsegA || !g.zsegB) && g.nseg > MAXSEG) return hipErrorInvalidValue;
 #define MPSK_DISPATCH(TA_, TB_)                                                        \
   return aligned ? launch_tile<TA_, TB_, true>(g, bm, bn, s) : launch_tile<TA_, TB_, false>(g, bm, bn, s)
   if (!g.transA && !g.transB) { MPSK_DISPATCH(false, false); }

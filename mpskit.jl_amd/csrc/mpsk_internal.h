@@ -50,6 +50,10 @@ struct GemmArgs {
   double* sk_ws;
   // XCD grid (set by gemm_f64): the 8 XCDs' tile chunks are xcd_gx x xcd_gy rectangles of the tile grid (0: linear)
   int xcd_gx, xcd_gy;
+  // optional per-batch K-segment offsets (device arrays [batch][nseg], element offsets): batch z reads segment i at
+  // A + tabA/bsA offset + zsegA[z * nseg + i] (override segA / segB when set; nseg is uniform over the batches)
+  const int64_t* zsegA;
+  const int64_t* zsegB;
   int tag;                   // 1: matvec-stage launch (own kernel symbol + event profile)
   int tabs_even;             // caller guarantees every tabA/tabB entry is even (16-B aligned operands)
 };

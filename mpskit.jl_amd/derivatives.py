@@ -17,11 +17,20 @@ class MPO_ddC:  # MPO_∂∂C  derivatives.jl:6-9
 
 
 class MPO_ddAC:  # MPO_∂∂AC  derivatives.jl:11-15
+    """Built once per site visit, applied by every Krylov step: the first application prepares the device-side
+    operator (mpsk_hac_create: MPO tensor folded into the right environment where that saves the slab mix), every
+    application is then mpsk_hac_apply."""
+
     def __init__(self, be, o, leftenv, rightenv):
         self.be, self.o, self.leftenv, self.rightenv = be, o, leftenv, rightenv
+        self._hac = None
 
     def __call__(self, x: DTensor, out: DTensor = None):
-        return self.be.dAC(self.o, self.leftenv, self.rightenv, x, out=out)
+        if not hasattr(self.be, "hac_create"):                   # host stand-in backend of the CPU tests
+            return self.be.dAC(self.o, self.leftenv, self.rightenv, x, out=out)
+        if self._hac is None:
+            self._hac = self.be.hac_create(self.o, self.leftenv, self.rightenv)
+        return self._hac.apply(x, out=out)
 
     __mul__ = __call__
 

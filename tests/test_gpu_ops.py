@@ -64,6 +64,53 @@ def test_dAC(be, Dl, Dr, d, chis):
 
 
 @pytest.mark.parametrize("Dl,Dr,d,chis", CASES)
+def test_prepared_operator_matches_dAC(be, Dl, Dr, d, chis):
+    """mpsk_hac (the MPO_ddAC object, derivatives.jl:11-15): prepared once, applied many times == mpsk_dAC == oracle,
+    whichever factorisation the cost model picks; also with x in the blocked layout and a row-sharded left environment."""
+    from mpskit_jl_amd import dist as md
+    rng = np.random.default_rng(99 + Dl * 7 + Dr)
+    s = rand_slice(rng, len(chis), d, chis)
+    GL, GR = rand_env(rng, chis, Dl, Dl), rand_env(rng, chis, Dr, Dr)
+    H, dGL, dGR = dev_slice(be, s), be.upload_env(GL), be.upload_env(GR)
+    hac = be.hac_create(H, dGL, dGR)
+    for rep in range(2):
+        x = rng.standard_normal((Dl, d, Dr))
+        ref = mo.dAC(x, s, GL, GR)
+        assert relerr(be.download(hac.apply(be.upload(x))), ref) < RTOL * max(Dl, Dr)
+    if Dl % 2 == 0:
+        P = 2
+        xb = md.to_blocked(be, be.upload(x), P)
+        assert relerr(be.download(hac.apply(xb, nblk=P)), ref) < RTOL * max(Dl, Dr)
+        n = Dl // P
+        rows = md.rows_of_env(be, dGL, n, 2 * n)                         # second row block of every slab
+        hloc = be.hac_create(H, rows, dGR)
+        assert relerr(be.download(hloc.apply(xb, nblk=P)), ref[n:]) < RTOL * max(Dl, Dr)
+
+
+@pytest.mark.parametrize("model", ["heis", "heis1", "tfi", "hubbard", "tfi2"])
+def test_prepared_operator_model_slices(be, model):
+    """The MPOs of the BASELINE configs through the prepared operator (MPO folded into the right environment: two GEMM
+    launches, no slab mix) == oracle."""
+    import mpskit_jl_amd as mk
+    D = 96
+    rng = np.random.default_rng(3)
+    if model == "tfi2":
+        X = np.array([[0.0, 1], [1, 0]]); Z = np.array([[1.0, 0], [0, -1]]); E = np.eye(2)
+        Hg = mk.from_twosite(-(np.kron(Z, Z) + 0.65 * (np.kron(X, E) + np.kron(E, X))).reshape(2, 2, 2, 2), be=be)[0]
+        Ho = mo.tfi_twosite_mpo(1.3)[0]
+    else:
+        Hg = {"heis": lambda: mk.heisenberg_XXX(0.5, be=be), "heis1": lambda: mk.heisenberg_XXX(1.0, be=be),
+              "tfi": lambda: mk.transverse_field_ising(1.0, 0.7, be=be), "hubbard": lambda: mk.hubbard(1.0, 4.0, be=be)}[model]()[0]
+        Ho = {"heis": lambda: mo.heisenberg_mpo(0.5), "heis1": lambda: mo.heisenberg_mpo(1.0),
+              "tfi": lambda: mo.tfi_mpo(1.0, 0.7), "hubbard": lambda: mo.hubbard_mpo(1.0, 4.0)}[model]()[0]
+    GL, GR = rand_env(rng, Ho.chil, D, D), rand_env(rng, Ho.chir, D, D)
+    x = rng.standard_normal((D, Hg.d, D))
+    hac = be.hac_create(Hg, be.upload_env(GL), be.upload_env(GR))
+    assert hac.info()["mode"] == 1, hac.info()        # at D = 96 the saved mix pass / launch always pays
+    assert relerr(be.download(hac.apply(be.upload(x))), mo.dAC(x, Ho, GL, GR)) < RTOL * D
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", CASES)
 def test_dC(be, Dl, Dr, d, chis):
     rng = np.random.default_rng(5 + Dl)
     GL, GR = rand_env(rng, chis, Dl, Dl), rand_env(rng, chis, Dr, Dr)
