@@ -29,8 +29,17 @@
  *    mutex-protected; tests/test_gpu_threads.py drives two ctxs from two threads and compares
  *    bit-for-bit with the serial run.  mpsk_ctx_force_tile and mpsk_prof_* are process-wide
  *    diagnostics.
- *  - dtype: this round implements MPSK_F64 (real fp64 MFMA path).  MPSK_C128 is reserved and
- *    returns MPSK_ERR_UNSUPPORTED.
+ *  - dtype: MPSK_F64 (real fp64) everywhere; MPSK_C128 (complex128, the reference's default scalar type,
+ *    defaults.jl:18) for the matvec / transfer family: mpsk_dAC, mpsk_dC, mpsk_dAC2, mpsk_hac_*, mpsk_transfer_left,
+ *    mpsk_transfer_right.  A slice created with MPSK_C128 makes every tensor argument of a call that takes it complex;
+ *    the slice-less calls (mpsk_dC, pass-through transfers) follow mpsk_ctx_set_dtype.  Complex tensors are
+ *    INTERLEAVED complex128 in the same column-major index order (TensorKit / Julia Array{ComplexF64} storage); a
+ *    complex MPO slice takes interleaved scalars[2 odim^2] and dense blocks.  Internally a complex product runs on
+ *    the real fp64 MFMA core as two K-segments (re / im of the second operand, the first one through a loader that
+ *    multiplies by i): 4x the real flops, the complex optimum.  The remaining entry points (gauge steps, Krylov vector
+ *    helpers, mpsk_gemm, mpsk_regularize) are fp64 only this round and ignore the ctx dtype: a complex host runs
+ *    its vector arithmetic on the 2n doubles of an interleaved vector (real inner products suffice for the Hermitian
+ *    Lanczos solvers) and its QRpos / LQpos through the real embedding.
  */
 #ifndef MPSK_H
 #define MPSK_H
@@ -56,6 +65,7 @@ const char* mpsk_last_error(void);
 int mpsk_ctx_create(int device, mpsk_ctx** out);
 int mpsk_ctx_destroy(mpsk_ctx* ctx);
 int mpsk_ctx_set_stream(mpsk_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = default */
+int mpsk_ctx_set_dtype(mpsk_ctx* ctx, int dtype);              /* scalar type of the slice-less calls (mpsk_dC, ...) */
 int mpsk_ctx_get_stream(mpsk_ctx* ctx, void** hip_stream);
 int mpsk_ctx_get_device(mpsk_ctx* ctx, int* device);
 int mpsk_ctx_synchronize(mpsk_ctx* ctx);

@@ -51,6 +51,7 @@ SIGNATURES = {
                  C.c_void_p],
     "mpsk_dAC_blocked": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                          C.c_void_p, C.c_void_p],
+    "mpsk_ctx_set_dtype": [C.c_void_p, C.c_int],
     "mpsk_ctx_get_stream": [C.c_void_p, c_void_pp],
     "mpsk_ctx_get_device": [C.c_void_p, C.POINTER(C.c_int)],
     "mpsk_hac_create": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_void_pp],

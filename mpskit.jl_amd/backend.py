@@ -136,6 +136,42 @@ class Backend:
         flat = t.buf[: t.size].cpu().numpy()
         return flat.reshape(t.shape, order="F").copy()
 
+    # ---- complex128 tensors: interleaved (re, im) = a REAL tensor whose first dimension is doubled ("half-embedded"
+    # view, include/mpsk.h); the complex operator paths take such DTensors (flag cplx / a complex MPO slice)
+    def upload_c(self, a):
+        """complex ndarray (logical index order) -> device, interleaved complex128 column-major; shape (2 n0, n1, ...)."""
+        torch = _torch()
+        a = np.asarray(a, dtype=np.complex128)
+        flat = np.ravel(a, order="F").view(np.float64)
+        buf = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
+        return DTensor(buf, (2 * a.shape[0],) + tuple(a.shape[1:]))
+
+    def download_c(self, t: DTensor):
+        flat = t.buf[: t.size].cpu().numpy().view(np.complex128)
+        return flat.reshape((t.shape[0] // 2,) + tuple(t.shape[1:]), order="F").copy()
+
+    def upload_env_c(self, blocks):
+        """complex env = list of [Dbra, chi_i, Dket] arrays -> device (W, 2 Dbra, Dket) interleaved slabs."""
+        torch = _torch()
+        slabs = [np.asarray(b, dtype=np.complex128)[:, k, :] for b in blocks for k in range(np.asarray(b).shape[1])]
+        flat = np.concatenate([np.ravel(s_, order="F") for s_ in slabs]).view(np.float64)
+        buf = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
+        return DTensor(buf, (len(slabs), 2 * slabs[0].shape[0], slabs[0].shape[1]))
+
+    def download_env_c(self, t: DTensor, chis):
+        W, Db2, Dk = t.shape
+        flat = t.buf[: t.size].cpu().numpy().view(np.complex128)
+        Db = Db2 // 2
+        slabs = [flat[w * Db * Dk:(w + 1) * Db * Dk].reshape((Db, Dk), order="F") for w in range(W)]
+        out, o = [], 0
+        for chi in chis:
+            out.append(np.stack(slabs[o:o + chi], axis=1))
+            o += chi
+        return out
+
+    def _set_dtype(self, cplx):
+        check(self.lib.mpsk_ctx_set_dtype(self.ctx, 1 if cplx else 0), "mpsk_ctx_set_dtype")
+
     def upload_env(self, blocks):
         """reference env = list of [Dbra, chi_i, Dket] arrays -> device (W, Dbra, Dket) slabs."""
         slabs = []
@@ -165,12 +201,20 @@ class Backend:
         return DTensor(t.buf.clone(), t.shape)
 
     # ---- MPO slices -----------------------------------------------------------------------
-    def mposlice(self, odim, d, chil, chir, blocks):
-        """blocks: {(i, j): scalar | ndarray [chi_i, d, d, chi_j]} (0-based levels)."""
-        return DeviceMPOSlice(self, odim, d, chil, chir, blocks)
+    def mposlice(self, odim, d, chil, chir, blocks, cplx=False):
+        """blocks: {(i, j): scalar | ndarray [chi_i, d, d, chi_j]} (0-based levels).  cplx: an MPSK_C128 slice (complex
+        entries allowed; every operand of a call that takes it is an interleaved complex128 tensor)."""
+        return DeviceMPOSlice(self, odim, d, chil, chir, blocks, cplx=cplx)
 
     # ---- hot-path operators ----------------------------------------------------------------
     def dAC(self, H, GL: DTensor, GR: DTensor, x: DTensor, out: DTensor = None):
+        if getattr(H, "cplx", False):          # interleaved complex128 operands: first dimensions are doubled
+            Dl2x, d, Dr = x.shape
+            Wl, Dlo2, Dl = GL.shape
+            assert Dl2x == 2 * Dl and GR.shape == (H.Wr, 2 * Dr, Dr) and Wl == H.Wl and d == H.d, (GL.shape, GR.shape, x.shape)
+            y = self.empty(Dlo2, d, Dr) if out is None else out
+            check(self.lib.mpsk_dAC(self.ctx, H.handle, Dlo2 // 2, Dl, Dr, GL.ptr, GR.ptr, x.ptr, y.ptr), "mpsk_dAC")
+            return y
         Dl, d, Dr = x.shape
         Wl, Dlo, Dl2 = GL.shape
         assert Dl2 == Dl and GR.shape == (H.Wr, Dr, Dr) and Wl == H.Wl and d == H.d, (GL.shape, GR.shape, x.shape)
@@ -194,7 +238,18 @@ class Backend:
         keeps GL / GR alive and releases the device-side object when it is garbage collected."""
         return PreparedHAC(self, H, GL, GR)
 
-    def dC(self, GL: DTensor, GR: DTensor, c: DTensor, out: DTensor = None):
+    def dC(self, GL: DTensor, GR: DTensor, c: DTensor, out: DTensor = None, cplx=False):
+        if cplx:
+            Dl2, Dr = c.shape
+            W, Dlo2, Dl = GL.shape
+            assert Dl2 == 2 * Dl and GR.shape == (W, 2 * Dr, Dr)
+            y = self.empty(Dlo2, Dr) if out is None else out
+            self._set_dtype(True)
+            try:
+                check(self.lib.mpsk_dC(self.ctx, W, Dlo2 // 2, Dl, Dr, GL.ptr, GR.ptr, c.ptr, y.ptr), "mpsk_dC")
+            finally:
+                self._set_dtype(False)
+            return y
         Dl, Dr = c.shape
         W, Dlo, _ = GL.shape
         assert GR.shape == (W, Dr, Dr)
@@ -203,6 +258,14 @@ class Backend:
         return y
 
     def dAC2(self, H1, H2, GL: DTensor, GR: DTensor, x2: DTensor, out: DTensor = None):
+        if getattr(H1, "cplx", False):
+            Dl2, d1, Dr, d2 = x2.shape
+            Wl, Dlo2, Dl = GL.shape
+            assert Dl2 == 2 * Dl and GR.shape == (H2.Wr, 2 * Dr, Dr) and Wl == H1.Wl
+            y = self.empty(Dlo2, d1, Dr, d2) if out is None else out
+            check(self.lib.mpsk_dAC2(self.ctx, H1.handle, H2.handle, Dlo2 // 2, Dl, Dr, GL.ptr, GR.ptr, x2.ptr, y.ptr),
+                  "mpsk_dAC2")
+            return y
         Dl, d1, Dr, d2 = x2.shape
         Wl, Dlo, _ = GL.shape
         assert GR.shape == (H2.Wr, Dr, Dr) and Wl == H1.Wl
@@ -211,7 +274,22 @@ class Backend:
               "mpsk_dAC2")
         return y
 
-    def transfer_left(self, H, GLin: DTensor, A: DTensor, Ab: DTensor, out: DTensor = None):
+    def transfer_left(self, H, GLin: DTensor, A: DTensor, Ab: DTensor, out: DTensor = None, cplx=False):
+        if cplx or getattr(H, "cplx", False):
+            Dl, d, Dr = A.shape[0] // 2, A.shape[1], A.shape[2]
+            Dlb, Drb = Ab.shape[0] // 2, Ab.shape[2]
+            W = GLin.shape[0]
+            Wout = H.Wr if H is not None else W
+            y = self.empty(Wout, 2 * Drb, Dr) if out is None else out
+            if H is None:
+                self._set_dtype(True)
+            try:
+                check(self.lib.mpsk_transfer_left(self.ctx, H.handle if H is not None else None, W, d, Dl, Dr, Dlb, Drb,
+                                                  GLin.ptr, A.ptr, Ab.ptr, y.ptr), "mpsk_transfer_left")
+            finally:
+                if H is None:
+                    self._set_dtype(False)
+            return y
         Dl, d, Dr = A.shape
         Dlb, _, Drb = Ab.shape
         W = GLin.shape[0]
@@ -221,7 +299,22 @@ class Backend:
                                           GLin.ptr, A.ptr, Ab.ptr, y.ptr), "mpsk_transfer_left")
         return y
 
-    def transfer_right(self, H, GRin: DTensor, A: DTensor, Ab: DTensor, out: DTensor = None):
+    def transfer_right(self, H, GRin: DTensor, A: DTensor, Ab: DTensor, out: DTensor = None, cplx=False):
+        if cplx or getattr(H, "cplx", False):
+            Dl, d, Dr = A.shape[0] // 2, A.shape[1], A.shape[2]
+            Dlb, Drb = Ab.shape[0] // 2, Ab.shape[2]
+            W = GRin.shape[0]
+            Wout = H.Wl if H is not None else W
+            y = self.empty(Wout, 2 * Dl, Dlb) if out is None else out
+            if H is None:
+                self._set_dtype(True)
+            try:
+                check(self.lib.mpsk_transfer_right(self.ctx, H.handle if H is not None else None, W, d, Dl, Dr, Dlb, Drb,
+                                                   A.ptr, Ab.ptr, GRin.ptr, y.ptr), "mpsk_transfer_right")
+            finally:
+                if H is None:
+                    self._set_dtype(False)
+            return y
         Dl, d, Dr = A.shape
         Dlb, _, Drb = Ab.shape
         W = GRin.shape[0]
@@ -395,8 +488,11 @@ class PreparedHAC:
 
     def __init__(self, be: Backend, H, GL: DTensor, GR: DTensor):
         Wl, Dlo, Dl = GL.shape
-        Wr, Dr, Dr2 = GR.shape
-        assert Wl == H.Wl and Wr == H.Wr and Dr == Dr2, (GL.shape, GR.shape)
+        Wr, Dr2, Dr = GR.shape
+        self.cplx = bool(getattr(H, "cplx", False))
+        m = 2 if self.cplx else 1                                   # interleaved complex: doubled first dimensions
+        Dlo //= m
+        assert Wl == H.Wl and Wr == H.Wr and Dr2 == m * Dr, (GL.shape, GR.shape)
         self.be, self.H, self.GL, self.GR = be, H, GL, GR           # references keep the operands alive
         self.Dlo, self.Dl, self.Dr, self.d = Dlo, Dl, Dr, H.d
         h = C.c_void_p()
@@ -409,8 +505,9 @@ class PreparedHAC:
         return {"mode": mode.value, "combined_slabs": ns.value}
 
     def apply(self, x: DTensor, out: DTensor = None, nblk=1):
-        assert x.shape == (self.Dl, self.d, self.Dr), (x.shape, (self.Dl, self.d, self.Dr))
-        y = self.be.empty(self.Dlo, self.d, self.Dr) if out is None else out
+        m = 2 if self.cplx else 1
+        assert x.shape == (m * self.Dl, self.d, self.Dr), (x.shape, (m * self.Dl, self.d, self.Dr))
+        y = self.be.empty(m * self.Dlo, self.d, self.Dr) if out is None else out
         check(self.be.lib.mpsk_hac_apply(self.handle, x.ptr, int(nblk), y.ptr), "mpsk_hac_apply")
         return y
 
@@ -430,41 +527,47 @@ class DeviceMPOSlice:
     """Device-side SparseMPOSlice (sparseslice.jl:13-27): keeps the host block table for the
     host-side logic (keys / isscal / contains) and an mpsk_mposlice handle for the kernels."""
 
-    def __init__(self, be: Backend, odim, d, chil, chir, blocks):
+    def __init__(self, be: Backend, odim, d, chil, chir, blocks, cplx=False):
         self.be = be
+        self.cplx = bool(cplx)
         self.odim, self.d = int(odim), int(d)
         self.chil, self.chir = [int(c) for c in chil], [int(c) for c in chir]
         self.Wl, self.Wr = sum(self.chil), sum(self.chir)
         self.blocks = dict(blocks)
         n = self.odim
         kind = (C.c_int32 * (n * n))()
-        scal = (C.c_double * (n * n))()
+        scal = (C.c_double * ((2 if self.cplx else 1) * n * n))()
         ptrs = (C.c_void_p * (n * n))()
         keep = []
         for (i, j), v in self.blocks.items():
             if np.isscalar(v):
-                if np.iscomplexobj(v) and complex(v).imag != 0:
-                    raise MpskError("complex MPO entries are not supported by the fp64 device path")
+                if not self.cplx and np.iscomplexobj(v) and complex(v).imag != 0:
+                    raise MpskError("complex MPO entries need an MPSK_C128 slice (mposlice(..., cplx=True))")
                 if v == 0:
                     continue
                 kind[i + n * j] = 1
-                scal[i + n * j] = float(np.real(v))
+                if self.cplx:
+                    scal[2 * (i + n * j)], scal[2 * (i + n * j) + 1] = float(np.real(v)), float(np.imag(v))
+                else:
+                    scal[i + n * j] = float(np.real(v))
             else:
                 a = np.asarray(v)
-                if np.iscomplexobj(a):
+                if np.iscomplexobj(a) and not self.cplx:
                     if np.abs(a.imag).max() > 0:
-                        raise MpskError("complex MPO entries are not supported by the fp64 device path")
+                        raise MpskError("complex MPO entries need an MPSK_C128 slice (mposlice(..., cplx=True))")
                     a = a.real
-                a = np.asfortranarray(a, dtype=np.float64)
                 assert a.shape == (self.chil[i], d, d, self.chir[j]), (a.shape, i, j)
-                flat = np.ravel(a, order="F").copy()
+                if self.cplx:
+                    flat = np.ravel(np.asarray(a, dtype=np.complex128), order="F").view(np.float64).copy()
+                else:
+                    flat = np.ravel(np.asfortranarray(a, dtype=np.float64), order="F").copy()
                 keep.append(flat)
                 kind[i + n * j] = 2
                 ptrs[i + n * j] = flat.ctypes.data
         h = C.c_void_p()
         cl = (C.c_int32 * n)(*self.chil)
         cr = (C.c_int32 * n)(*self.chir)
-        check(be.lib.mpsk_mposlice_create(be.ctx, 0, n, cl, cr, self.d, kind, scal, ptrs, C.byref(h)),
+        check(be.lib.mpsk_mposlice_create(be.ctx, 1 if self.cplx else 0, n, cl, cr, self.d, kind, scal, ptrs, C.byref(h)),
               "mpsk_mposlice_create")
         self.handle = h
 

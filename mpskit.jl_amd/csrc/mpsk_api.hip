@@ -29,9 +29,15 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct mpsk_mposlice {
   mpsk_ctx* ctx;
   int Wl, Wr, d;
+  int dtype = MPSK_F64;       // MPSK_C128: complex entries (Ofull_im), every operand of a call with this slice is complex128
   std::vector<double> Ofull;  // [Wl, d, d, Wr] column-major, index (w,t,s,v)
+  std::vector<double> Ofull_im;
   MixPlan fwd;                // (w,s) -> (v,t)   in = s + d*w, out = t + d*v
   MixPlan bwd;                // (v,t) -> (w,s)   in = t + d*v, out = s + d*w
+  MixPlan rgt;                // (v,s) -> (w,t)   in = s + d*v, out = t + d*w   (complex transfer_right: A GR first, then Ab^H)
+  double Oi(int w, int t, int s, int v) const {
+    return Ofull_im.empty() ? 0.0 : Ofull_im[w + (size_t)Wl * (t + d * (s + (size_t)d * v))];
+  }
   std::vector<char> row_used, col_used;
   // "right-combined" form of the matvec (mpsk_hac): the MPO tensor is folded into the right environment once per
   // site visit,  GRc[c] = sum_v O[w_c, t_c, s_c, v] GR[v]  for every (w, s, t) with a non-zero entry, so that
@@ -52,6 +58,7 @@ struct mpsk_ctx {
   double* d_scal = nullptr;     // [MAXK] device scalars
   double* d_partial = nullptr;  // dot scratch
   double* h_scal = nullptr;     // pinned host mirror
+  int dtype = MPSK_F64;         // scalar type of the slice-less entry points (mpsk_ctx_set_dtype)
   int last_svd_sweeps = 0;
   int svd_precondition = 1;     // QR-preconditioned Jacobi (mpsk_ctx_set_svd_mode)
   int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
@@ -147,6 +154,12 @@ int mpsk_ctx_set_stream(mpsk_ctx* c, void* s) {
   return MPSK_OK;
 }
 
+int mpsk_ctx_set_dtype(mpsk_ctx* c, int dtype) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE(dtype == MPSK_F64 || dtype == MPSK_C128, "dtype must be MPSK_F64 or MPSK_C128");
+  c->dtype = dtype;
+  return MPSK_OK;
+}
 int mpsk_ctx_get_stream(mpsk_ctx* c, void** s) {
   REQUIRE(c && s, "NULL argument");
   *s = (void*)c->stream;
@@ -237,7 +250,8 @@ int mpsk_mposlice_create(mpsk_ctx* c, int dtype, int odim, const int32_t* chi_l,
                          int d, const int32_t* kind, const double* scalars, const void* const* blocks,
                          mpsk_mposlice** out) {
   REQUIRE(c && out && chi_l && chi_r && kind, "NULL argument");
-  if (dtype != MPSK_F64) return fail(MPSK_ERR_UNSUPPORTED, "only MPSK_F64 is implemented");
+  REQUIRE(dtype == MPSK_F64 || dtype == MPSK_C128, "dtype must be MPSK_F64 or MPSK_C128");
+  const bool cx = dtype == MPSK_C128;     // scalars / dense blocks are then interleaved complex128 (re, im)
   REQUIRE(odim > 0 && d > 0, "odim and d must be positive");
   HIPCHK(hipSetDevice(c->device));
   std::vector<int> offl(odim + 1, 0), offr(odim + 1, 0);
@@ -247,10 +261,14 @@ int mpsk_mposlice_create(mpsk_ctx* c, int dtype, int odim, const int32_t* chi_l,
     offr[i + 1] = offr[i] + chi_r[i];
   }
   auto* s = new mpsk_mposlice();
-  s->ctx = c; s->Wl = offl[odim]; s->Wr = offr[odim]; s->d = d;
+  s->ctx = c; s->Wl = offl[odim]; s->Wr = offr[odim]; s->d = d; s->dtype = dtype;
   s->Ofull.assign((size_t)s->Wl * d * d * s->Wr, 0.0);
+  if (cx) s->Ofull_im.assign(s->Ofull.size(), 0.0);
   auto at = [&](int w, int t, int si, int v) -> double& {
     return s->Ofull[w + (size_t)s->Wl * (t + d * (si + (size_t)d * v))];
+  };
+  auto ati = [&](int w, int t, int si, int v) -> double& {
+    return s->Ofull_im[w + (size_t)s->Wl * (t + d * (si + (size_t)d * v))];
   };
   for (int j = 0; j < odim; ++j)
     for (int i = 0; i < odim; ++i) {
@@ -258,9 +276,13 @@ int mpsk_mposlice_create(mpsk_ctx* c, int dtype, int odim, const int32_t* chi_l,
       if (k == MPSK_BLOCK_ZERO) continue;
       if (k == MPSK_BLOCK_SCALAR) {
         if (!scalars || chi_l[i] != chi_r[j]) { delete s; return fail(MPSK_ERR_INVALID, "scalar block needs scalars[] and chi_l[i] == chi_r[j]"); }
-        double cv = scalars[i + odim * j];
+        const size_t e = (size_t)i + (size_t)odim * j;
+        const double cv = cx ? scalars[2 * e] : scalars[e], ci = cx ? scalars[2 * e + 1] : 0.0;
         for (int a = 0; a < chi_l[i]; ++a)
-          for (int t = 0; t < d; ++t) at(offl[i] + a, t, t, offr[j] + a) = cv;
+          for (int t = 0; t < d; ++t) {
+            at(offl[i] + a, t, t, offr[j] + a) = cv;
+            if (cx) ati(offl[i] + a, t, t, offr[j] + a) = ci;
+          }
       } else if (k == MPSK_BLOCK_DENSE) {
         if (!blocks || !blocks[i + odim * j]) { delete s; return fail(MPSK_ERR_INVALID, "dense block pointer is NULL"); }
         const double* b = (const double*)blocks[i + odim * j];
@@ -268,25 +290,30 @@ int mpsk_mposlice_create(mpsk_ctx* c, int dtype, int odim, const int32_t* chi_l,
         for (int v = 0; v < cr; ++v)
           for (int si = 0; si < d; ++si)
             for (int t = 0; t < d; ++t)
-              for (int w = 0; w < cl; ++w)
-                at(offl[i] + w, t, si, offr[j] + v) = b[w + (size_t)cl * (t + d * (si + (size_t)d * v))];
+              for (int w = 0; w < cl; ++w) {
+                const size_t e = w + (size_t)cl * (t + d * (si + (size_t)d * v));
+                at(offl[i] + w, t, si, offr[j] + v) = cx ? b[2 * e] : b[e];
+                if (cx) ati(offl[i] + w, t, si, offr[j] + v) = b[2 * e + 1];
+              }
       } else { delete s; return fail(MPSK_ERR_INVALID, "bad block kind"); }
     }
-  std::vector<MixTerm> fwd, bwd;
+  std::vector<MixTerm> fwd, bwd, rgt;
   s->row_used.assign(s->Wl, 0); s->col_used.assign(s->Wr, 0);
   for (int v = 0; v < s->Wr; ++v)
     for (int si = 0; si < d; ++si)
       for (int t = 0; t < d; ++t)
         for (int w = 0; w < s->Wl; ++w) {
-          double cv = s->O(w, t, si, v);
-          if (cv == 0.0) continue;
-          fwd.push_back({t + d * v, si + d * w, cv});
-          bwd.push_back({si + d * w, t + d * v, cv});
+          const double cv = s->O(w, t, si, v), ci = s->Oi(w, t, si, v);
+          if (cv == 0.0 && ci == 0.0) continue;
+          fwd.push_back({t + d * v, si + d * w, cv, ci});
+          bwd.push_back({si + d * w, t + d * v, cv, ci});
+          rgt.push_back({t + d * w, si + d * v, cv, ci});
           s->row_used[w] = 1; s->col_used[v] = 1;
         }
   HIPCHK(mix_plan_create(fwd, d * s->Wr, d * s->Wl, &s->fwd));
   HIPCHK(mix_plan_create(bwd, d * s->Wl, d * s->Wr, &s->bwd));
-  {  // right-combined plan
+  HIPCHK(mix_plan_create(rgt, d * s->Wl, d * s->Wr, &s->rgt));
+  if (!cx) {  // right-combined plan (real slices; complex operators use the mix form)
     std::vector<MixTerm> rc;
     std::vector<int> per_t(d, 0);
     for (int t = 0; t < d; ++t)
@@ -315,6 +342,7 @@ int mpsk_mposlice_destroy(mpsk_mposlice* s) {
   }
   mix_plan_destroy(&s->fwd);
   mix_plan_destroy(&s->bwd);
+  mix_plan_destroy(&s->rgt);
   mix_plan_destroy(&s->rc);
   delete s;
   return MPSK_OK;
@@ -349,14 +377,17 @@ static GemmArgs mk(const double* A, const double* B, double* C, int M, int N, in
 
 // run a GEMM whose K dimension is a list of segments longer than MAXSEG by chunking (beta = 1)
 static hipError_t gemm_segments(GemmArgs g, const std::vector<int64_t>& sa, const std::vector<int64_t>& sb,
-                                hipStream_t s) {
+                                hipStream_t s, const std::vector<int>* sj = nullptr) {
   size_t n = sa.size();
   if (n == 0) return hipErrorInvalidValue;
   double beta0 = g.beta;
   for (size_t i0 = 0; i0 < n; i0 += MAXSEG) {
     int ns = (int)std::min<size_t>(MAXSEG, n - i0);
     g.nseg = ns;
-    for (int i = 0; i < ns; ++i) { g.segA[i] = sa[i0 + i]; g.segB[i] = sb[i0 + i]; }
+    for (int i = 0; i < ns; ++i) {
+      g.segA[i] = sa[i0 + i]; g.segB[i] = sb[i0 + i];
+      g.segJ[i] = sj ? (signed char)(*sj)[i0 + i] : 0;
+    }
     g.beta = (i0 == 0) ? beta0 : 1.0;
     hipError_t e = gemm_f64(g, s);
     if (e != hipSuccess) return e;
@@ -371,6 +402,180 @@ extern "C" {
 // --------------------------------------------------------------------------------------------
 // derivatives
 // --------------------------------------------------------------------------------------------
+// ---- complex128 operators -----------------------------------------------------------------------------------------
+// Every complex tensor argument is interleaved complex128 in TensorKit / Julia layout = a REAL column-major tensor whose
+// first dimension is doubled, rows (2 a, 2 a + 1) = (re, im) of row a.  With A_half such a view and B = Br + i Bi:
+//   (A B)_half = A_half Br + (J A_half) Bi ,     J (re, im) = (-im, re)
+// so a complex product is the real GEMM core with two K-segments (the second through the J-aware A loader, GemmArgs::segJ)
+// on a B operand split into planes -- 4x the real flops, the complex optimum; intermediates stay interleaved.
+static hipError_t cx_planes(const double* z, size_t n, double* re, double* im, hipStream_t s) {     // interleaved -> planar
+  hipError_t e = copy_strided(z, 2, 0, re, 1, 0, (int64_t)n, 1, s);
+  if (e != hipSuccess) return e;
+  return copy_strided(z + 1, 2, 0, im, 1, 0, (int64_t)n, 1, s);
+}
+static size_t ev2(size_t v) { return (v + 1) & ~(size_t)1; }
+
+// GRp: planar copy of GR ([re plane | im plane], each Wr Dr Dr doubles) if the caller has one (prepared operator), else null
+static int dAC_c128(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const double* GL, const double* GR,
+                    const double* GRp, const double* x, double* y) {   // GRp planes are ev2(Wr Dr Dr) doubles apart
+  HIPCHK(hipSetDevice(c->device));
+  const int d = H->d, Wl = H->Wl, Wr = H->Wr;
+  const size_t nx = (size_t)Dl * d * Dr, nG = (size_t)Wr * Dr * Dr, slab = (size_t)2 * Dlo * d * Dr;
+  const size_t o_g = 2 * ev2(nx), o_t1 = o_g + (GRp ? 0 : 2 * ev2(nG)), o_t2 = o_t1 + slab * Wl;
+  if (int rc = ensure_ws(c, sizeof(double) * (o_t2 + slab * Wr))) return rc;
+  double* xp = (double*)c->ws;
+  double* T1 = xp + o_t1;
+  double* T2 = xp + o_t2;
+  HIPCHK(cx_planes(x, nx, xp, xp + ev2(nx), c->stream));
+  const double* gr = GRp;
+  size_t gplane = ev2(nG);
+  if (!gr) { double* g = xp + o_g; HIPCHK(cx_planes(GR, nG, g, g + ev2(nG), c->stream)); gr = g; gplane = ev2(nG); }
+  // stage 1: T1[w] = GL[w] x
+  GemmArgs g1 = mk(GL, xp, T1, 2 * Dlo, d * Dr, Dl, 2 * Dlo, Dl, 2 * Dlo);
+  g1.batch = Wl; g1.bsA = (int64_t)2 * Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.nseg = 2; g1.segA[0] = g1.segA[1] = 0; g1.segB[0] = 0; g1.segB[1] = (int64_t)ev2(nx); g1.segJ[0] = 0; g1.segJ[1] = 1;
+  g1.cplx = 1;
+  HIPCHK(gemm_f64(g1, c->stream));
+  SlabIndex ix{d, 1 << 30, (int64_t)2 * Dlo, (int64_t)slab, 0, (int64_t)2 * Dlo * d};
+  HIPCHK(mix_apply(H->fwd, T1, ix, T2, ix, 2 * Dlo, Dr, c->stream));
+  std::vector<int64_t> sa, sb;
+  std::vector<int> sj;
+  for (int v = 0; v < Wr; ++v)
+    if (H->col_used[v])
+      for (int pl = 0; pl < 2; ++pl) { sa.push_back((int64_t)v * slab); sb.push_back((int64_t)(pl * gplane + (size_t)v * Dr * Dr)); sj.push_back(pl); }
+  if (sa.empty()) { HIPCHK(zero_async(y, sizeof(double) * slab, c->stream)); return MPSK_OK; }
+  GemmArgs g3 = mk(T2, gr, y, 2 * Dlo * d, Dr, Dr, (int64_t)2 * Dlo * d, Dr, (int64_t)2 * Dlo * d);
+  g3.cplx = 1;
+  HIPCHK(gemm_segments(g3, sa, sb, c->stream, &sj));
+  return MPSK_OK;
+}
+
+static int dC_c128(mpsk_ctx* c, int W, int Dlo, int Dl, int Dr, const double* GL, const double* GR, const double* cm,
+                   double* y) {
+  HIPCHK(hipSetDevice(c->device));
+  const size_t nx = (size_t)Dl * Dr, nG = (size_t)W * Dr * Dr, slab = (size_t)2 * Dlo * Dr;
+  const size_t o_g = 2 * ev2(nx), o_t1 = o_g + 2 * ev2(nG);
+  if (int rc = ensure_ws(c, sizeof(double) * (o_t1 + slab * W))) return rc;
+  double* xp = (double*)c->ws;
+  double* g = xp + o_g;
+  double* T1 = xp + o_t1;
+  HIPCHK(cx_planes(cm, nx, xp, xp + ev2(nx), c->stream));
+  HIPCHK(cx_planes(GR, nG, g, g + ev2(nG), c->stream));
+  GemmArgs g1 = mk(GL, xp, T1, 2 * Dlo, Dr, Dl, 2 * Dlo, Dl, 2 * Dlo);
+  g1.batch = W; g1.bsA = (int64_t)2 * Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.nseg = 2; g1.segB[1] = (int64_t)ev2(nx); g1.segJ[1] = 1; g1.cplx = 1;
+  HIPCHK(gemm_f64(g1, c->stream));
+  std::vector<int64_t> sa, sb;
+  std::vector<int> sj;
+  for (int w = 0; w < W; ++w)
+    for (int pl = 0; pl < 2; ++pl) { sa.push_back((int64_t)w * slab); sb.push_back((int64_t)(pl * ev2(nG) + (size_t)w * Dr * Dr)); sj.push_back(pl); }
+  GemmArgs g3 = mk(T1, g, y, 2 * Dlo, Dr, Dr, 2 * Dlo, Dr, 2 * Dlo);
+  g3.cplx = 1;
+  HIPCHK(gemm_segments(g3, sa, sb, c->stream, &sj));
+  return MPSK_OK;
+}
+
+static int pair_plan(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* H2, const MixPlan** out);
+
+static int dAC2_c128(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* H2, int Dlo, int Dl, int Dr,
+                     const double* GL, const double* GR, const double* x2, double* y2) {
+  HIPCHK(hipSetDevice(c->device));
+  const int d1 = H1->d, d2 = H2->d, Wl = H1->Wl, Wr = H2->Wr;
+  const size_t nx = (size_t)Dl * d1 * Dr * d2, nG = (size_t)Wr * Dr * Dr;
+  const size_t plane = (size_t)2 * Dlo * d1 * Dr, slab = plane * d2;
+  const size_t o_g = 2 * ev2(nx), o_t1 = o_g + 2 * ev2(nG), o_t2 = o_t1 + slab * Wl;
+  if (int rc = ensure_ws(c, sizeof(double) * (o_t2 + slab * Wr))) return rc;
+  double* xp = (double*)c->ws;
+  double* g = xp + o_g;
+  double* T1 = xp + o_t1;
+  double* T2 = xp + o_t2;
+  const MixPlan* plan = nullptr;
+  if (int rc = pair_plan(c, H1, H2, &plan)) return rc;
+  HIPCHK(cx_planes(x2, nx, xp, xp + ev2(nx), c->stream));
+  HIPCHK(cx_planes(GR, nG, g, g + ev2(nG), c->stream));
+  GemmArgs g1 = mk(GL, xp, T1, 2 * Dlo, d1 * Dr * d2, Dl, 2 * Dlo, Dl, 2 * Dlo);
+  g1.batch = Wl; g1.bsA = (int64_t)2 * Dlo * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.nseg = 2; g1.segB[1] = (int64_t)ev2(nx); g1.segJ[1] = 1; g1.cplx = 1;
+  HIPCHK(gemm_f64(g1, c->stream));
+  SlabIndex ix{d1, d2, (int64_t)2 * Dlo, (int64_t)plane, (int64_t)slab, (int64_t)2 * Dlo * d1};
+  HIPCHK(mix_apply(*plan, T1, ix, T2, ix, 2 * Dlo, Dr, c->stream));
+  std::vector<int64_t> sa, sb;
+  std::vector<int> sj;
+  for (int v = 0; v < Wr; ++v)
+    if (H2->col_used[v])
+      for (int pl = 0; pl < 2; ++pl) { sa.push_back((int64_t)v * slab); sb.push_back((int64_t)(pl * ev2(nG) + (size_t)v * Dr * Dr)); sj.push_back(pl); }
+  if (sa.empty()) { HIPCHK(zero_async(y2, sizeof(double) * slab, c->stream)); return MPSK_OK; }
+  GemmArgs g3 = mk(T2, g, y2, 2 * Dlo * d1, Dr, Dr, (int64_t)2 * Dlo * d1, Dr, (int64_t)2 * Dlo * d1);
+  g3.batch = d2; g3.bsA = (int64_t)plane; g3.bsB = 0; g3.bsC = (int64_t)plane; g3.cplx = 1;
+  HIPCHK(gemm_segments(g3, sa, sb, c->stream, &sj));
+  return MPSK_OK;
+}
+
+// GLout[v][q,b] = sum GLin[w][p,a] A[a,s,b] O[w,t,s,v] conj(Ab[p,t,q])
+static int transfer_left_c128(mpsk_ctx* c, const mpsk_mposlice* H, int W, int d, int Dl, int Dr, int Dlb, int Drb,
+                              const double* GLin, const double* A, const double* Ab, double* GLout) {
+  HIPCHK(hipSetDevice(c->device));
+  int Wl = W, Wr = W;
+  if (H) { Wl = H->Wl; Wr = H->Wr; d = H->d; }
+  const size_t nA = (size_t)Dl * d * Dr, slab = (size_t)2 * Dlb * d * Dr;
+  const size_t o_t1 = 2 * ev2(nA), o_t2 = o_t1 + slab * Wl;
+  if (int rc = ensure_ws(c, sizeof(double) * (o_t2 + (H ? slab * Wr : 0)))) return rc;
+  double* Ap = (double*)c->ws;
+  double* T1 = Ap + o_t1;
+  double* T2 = H ? Ap + o_t2 : T1;
+  HIPCHK(cx_planes(A, nA, Ap, Ap + ev2(nA), c->stream));
+  // T1[w] = GLin[w] A      (2 Dlb x d Dr, rows interleaved)
+  GemmArgs g1 = mk(GLin, Ap, T1, 2 * Dlb, d * Dr, Dl, 2 * Dlb, Dl, 2 * Dlb);
+  g1.batch = Wl; g1.bsA = (int64_t)2 * Dlb * Dl; g1.bsB = 0; g1.bsC = (int64_t)slab;
+  g1.nseg = 2; g1.segB[1] = (int64_t)ev2(nA); g1.segJ[1] = 1; g1.cplx = 1;
+  HIPCHK(gemm_f64(g1, c->stream));
+  if (H) {
+    SlabIndex ix{d, 1 << 30, (int64_t)2 * Dlb, (int64_t)slab, 0, (int64_t)2 * Dlb * d};
+    HIPCHK(mix_apply(H->fwd, T1, ix, T2, ix, 2 * Dlb, Dr, c->stream));
+  }
+  // GLout[v] = Ab^H T2[v]:  K = (re / im, p, t) interleaved on both operands ->  real part = Ab_half^T T2_half,
+  // imaginary part = (J Ab_half)^T T2_half ; plane alpha goes to the rows 2 q + alpha of the interleaved result
+  for (int al = 0; al < 2; ++al) {
+    GemmArgs g3 = mk(Ab, T2, GLout + al, Drb, Dr, 2 * Dlb * d, (int64_t)2 * Dlb * d, (int64_t)2 * Dlb * d, (int64_t)2 * Drb, 1, 0);
+    g3.batch = Wr; g3.bsA = 0; g3.bsB = (int64_t)slab; g3.bsC = (int64_t)2 * Drb * Dr;
+    g3.cplx = 1; g3.c_rs = 2; g3.segJ[0] = (signed char)al;
+    HIPCHK(gemm_f64(g3, c->stream));
+  }
+  return MPSK_OK;
+}
+
+// GRout[w][a,p] = sum A[a,s,b] O[w,t,s,v] conj(Ab[p,t,q]) GRin[v][b,q]   evaluated as  ((A GRin) mixed) Ab^H
+static int transfer_right_c128(mpsk_ctx* c, const mpsk_mposlice* H, int W, int d, int Dl, int Dr, int Dlb, int Drb,
+                               const double* A, const double* Ab, const double* GRin, double* GRout) {
+  HIPCHK(hipSetDevice(c->device));
+  int Wl = W, Wr = W;
+  if (H) { Wl = H->Wl; Wr = H->Wr; d = H->d; }
+  const size_t nG = (size_t)Wr * Dr * Drb, nB = (size_t)Dlb * d * Drb, slab = (size_t)2 * Dl * d * Drb;
+  const size_t o_b = 2 * ev2(nG), o_x = o_b + 2 * ev2(nB), o_y = o_x + slab * Wr;
+  if (int rc = ensure_ws(c, sizeof(double) * (o_y + (H ? slab * Wl : 0)))) return rc;
+  double* Gp = (double*)c->ws;
+  double* Bp = Gp + o_b;
+  double* X = Gp + o_x;
+  double* Y = H ? Gp + o_y : X;
+  HIPCHK(cx_planes(GRin, nG, Gp, Gp + ev2(nG), c->stream));
+  HIPCHK(cx_planes(Ab, nB, Bp, Bp + ev2(nB), c->stream));
+  // X[v][a,s,q] = sum_b A[a,s,b] GRin[v][b,q]      A as the (2 Dl d) x Dr interleaved matrix
+  GemmArgs g1 = mk(A, Gp, X, 2 * Dl * d, Drb, Dr, (int64_t)2 * Dl * d, Dr, (int64_t)2 * Dl * d);
+  g1.batch = Wr; g1.bsA = 0; g1.bsB = (int64_t)Dr * Drb; g1.bsC = (int64_t)slab;
+  g1.nseg = 2; g1.segB[1] = (int64_t)ev2(nG); g1.segJ[1] = 1; g1.cplx = 1;
+  HIPCHK(gemm_f64(g1, c->stream));
+  if (H) {   // Y[w][a,t,q] = sum_{v,s} O[w,t,s,v] X[v][a,s,q]
+    SlabIndex ix{d, 1 << 30, (int64_t)2 * Dl, (int64_t)slab, 0, (int64_t)2 * Dl * d};
+    HIPCHK(mix_apply(H->rgt, X, ix, Y, ix, 2 * Dl, Drb, c->stream));
+  }
+  // GRout[w][a,p] = sum_{t,q} Y[w][a,(t,q)] conj(Ab[p,(t,q)]) = Y_half Abr^T + (-J Y_half) Abi^T
+  GemmArgs g3 = mk(Y, Bp, GRout, 2 * Dl, Dlb, d * Drb, (int64_t)2 * Dl, Dlb, (int64_t)2 * Dl, 0, 1);
+  g3.batch = Wl; g3.bsA = (int64_t)slab; g3.bsB = 0; g3.bsC = (int64_t)2 * Dl * Dlb;
+  g3.nseg = 2; g3.segB[1] = (int64_t)ev2(nB); g3.segJ[1] = 2; g3.cplx = 1;
+  HIPCHK(gemm_f64(g3, c->stream));
+  return MPSK_OK;
+}
+
 // x may be given in `nblk` row blocks (block q = rows [q Dl/nblk, (q+1) Dl/nblk) as a contiguous [Dl/nblk, d, Dr]
 // tensor): the blocks become K-segments of the stage-1 GEMM, nothing is re-interleaved (mpsk_dAC_blocked).
 static int dAC_impl(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
@@ -406,6 +611,8 @@ int mpsk_dAC(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const
              const void* x, void* y) {
   REQUIRE(c && H && GL && GR && x && y, "NULL argument");
   REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  if (H->dtype == MPSK_C128)
+    return dAC_c128(c, H, Dlo, Dl, Dr, (const double*)GL, (const double*)GR, nullptr, (const double*)x, (double*)y);
   return dAC_impl(c, H, Dlo, Dl, Dr, GL, GR, x, 1, y);
 }
 
@@ -414,6 +621,10 @@ int mpsk_dAC_blocked(mpsk_ctx* c, const mpsk_mposlice* H, int nblk, int Dlo, int
   REQUIRE(c && H && GL && GR && xblk && y, "NULL argument");
   REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
   REQUIRE(nblk >= 1 && nblk <= MAXSEG && Dl % nblk == 0, "nblk must divide Dl (and be <= 32)");
+  if (H->dtype == MPSK_C128) {
+    if (nblk != 1) return fail(MPSK_ERR_UNSUPPORTED, "mpsk_dAC_blocked: the blocked layout is implemented for MPSK_F64 only");
+    return dAC_c128(c, H, Dlo, Dl, Dr, (const double*)GL, (const double*)GR, nullptr, (const double*)xblk, (double*)y);
+  }
   return dAC_impl(c, H, Dlo, Dl, Dr, GL, GR, xblk, nblk, y);
 }
 
@@ -459,6 +670,19 @@ int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr
   h->ctx = c; h->H = H; h->Dlo = Dlo; h->Dl = Dl; h->Dr = Dr; h->GL = (const double*)GL; h->GR = (const double*)GR;
   h->mode = (H->rc_nseg > 0 && t_rc <= t_mix) ? 1 : 0;
   if (const char* ev = getenv("MPSK_HAC_MODE")) h->mode = (ev[0] == '1' && H->rc_nseg > 0) ? 1 : 0;
+  if (H->dtype == MPSK_C128) {
+    // complex128: mix form; what is prepared once per site is the planar copy of the right environment (the B operand
+    // of stage 3), so that an application converts only x
+    h->mode = 2;
+    const size_t nG = (size_t)Wr * Dr * Dr;
+    void* buf = nullptr;
+    if (int rc = pool_take(c, sizeof(double) * 2 * ev2(nG), &buf, &h->pool_idx)) { delete h; return rc; }
+    h->GRc = (double*)buf;
+    hipError_t e = cx_planes((const double*)GR, nG, h->GRc, h->GRc + ev2(nG), c->stream);
+    if (e != hipSuccess) { c->pool[h->pool_idx].used = false; delete h; return fail(MPSK_ERR_HIP, hipGetErrorString(e)); }
+    *out = h;
+    return MPSK_OK;
+  }
   if (h->mode == 1) {
     const int nc = (int)H->rc_w.size(), ns = H->rc_nseg;
     const size_t slabR = (size_t)Dr * Dr;
@@ -512,6 +736,10 @@ int mpsk_hac_apply(mpsk_hac* h, const void* x, int nblk, void* y) {
   const mpsk_mposlice* H = h->H;
   const int Dlo = h->Dlo, Dl = h->Dl, Dr = h->Dr;
   REQUIRE(nblk >= 1 && nblk <= MAXSEG && Dl % nblk == 0, "nblk must divide Dl (and be <= 32)");
+  if (h->mode == 2) {
+    if (nblk != 1) return fail(MPSK_ERR_UNSUPPORTED, "mpsk_hac_apply: the blocked layout is implemented for MPSK_F64 only");
+    return dAC_c128(c, H, Dlo, Dl, Dr, h->GL, h->GR, h->GRc, (const double*)x, (double*)y);
+  }
   if (h->mode == 0) return dAC_impl(c, H, Dlo, Dl, Dr, h->GL, h->GR, x, nblk, y);
   HIPCHK(hipSetDevice(c->device));
   const int d = H->d, Wl = H->Wl, ns = H->rc_nseg;
@@ -539,6 +767,8 @@ int mpsk_hac_apply(mpsk_hac* h, const void* x, int nblk, void* y) {
 int mpsk_dC(mpsk_ctx* c, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR, const void* cm, void* y) {
   REQUIRE(c && GL && GR && cm && y, "NULL argument");
   REQUIRE(W > 0 && Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  if (c->dtype == MPSK_C128)
+    return dC_c128(c, W, Dlo, Dl, Dr, (const double*)GL, (const double*)GR, (const double*)cm, (double*)y);
   HIPCHK(hipSetDevice(c->device));
   const size_t slab = (size_t)Dlo * Dr;
   if (int rc = ensure_ws(c, sizeof(double) * slab * W)) return rc;
@@ -561,24 +791,28 @@ static int pair_plan(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* 
   if (it != c->pair_plans.end()) { *out = &it->second; return MPSK_OK; }
   const int d1 = H1->d, d2 = H2->d, Wl = H1->Wl, Wm = H1->Wr, Wr = H2->Wr;
   // O12[(t1,t2,v) <- (s1,s2,w)] = sum_u O1[w,t1,s1,u] O2[u,t2,s2,v]   (derivatives.jl:128-147)
-  std::map<std::pair<int, int>, double> acc;
+  std::map<std::pair<int, int>, std::pair<double, double>> acc;
   for (int u = 0; u < Wm; ++u)
     for (int w = 0; w < Wl; ++w)
       for (int t1 = 0; t1 < d1; ++t1)
         for (int s1 = 0; s1 < d1; ++s1) {
-          double a = H1->O(w, t1, s1, u);
-          if (a == 0.0) continue;
+          const double a = H1->O(w, t1, s1, u), ai = H1->Oi(w, t1, s1, u);
+          if (a == 0.0 && ai == 0.0) continue;
           for (int v = 0; v < Wr; ++v)
             for (int t2 = 0; t2 < d2; ++t2)
               for (int s2 = 0; s2 < d2; ++s2) {
-                double b = H2->O(u, t2, s2, v);
-                if (b == 0.0) continue;
+                const double b = H2->O(u, t2, s2, v), bi = H2->Oi(u, t2, s2, v);
+                if (b == 0.0 && bi == 0.0) continue;
                 int o = t1 + d1 * (t2 + d2 * v), in = s1 + d1 * (s2 + d2 * w);
-                acc[{o, in}] += a * b;
+                auto& e = acc[{o, in}];
+                e.first += a * b - ai * bi;
+                e.second += a * bi + ai * b;
               }
         }
   std::vector<MixTerm> terms;
-  for (auto& kv : acc) if (kv.second != 0.0) terms.push_back({kv.first.first, kv.first.second, kv.second});
+  for (auto& kv : acc)
+    if (kv.second.first != 0.0 || kv.second.second != 0.0)
+      terms.push_back({kv.first.first, kv.first.second, kv.second.first, kv.second.second});
   MixPlan p;
   HIPCHK(mix_plan_create(terms, d1 * d2 * Wr, d1 * d2 * Wl, &p));
   auto res = c->pair_plans.emplace(key, p);
@@ -591,6 +825,9 @@ int mpsk_dAC2(mpsk_ctx* c, const mpsk_mposlice* H1, const mpsk_mposlice* H2, int
   REQUIRE(c && H1 && H2 && GL && GR && x2 && y2, "NULL argument");
   REQUIRE(H1->Wr == H2->Wl, "MPO bond dimensions of the two slices do not match");
   REQUIRE(Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");
+  REQUIRE(H1->dtype == H2->dtype, "the two slices have different scalar types");
+  if (H1->dtype == MPSK_C128)
+    return dAC2_c128(c, H1, H2, Dlo, Dl, Dr, (const double*)GL, (const double*)GR, (const double*)x2, (double*)y2);
   HIPCHK(hipSetDevice(c->device));
   const int d1 = H1->d, d2 = H2->d, Wl = H1->Wl, Wr = H2->Wr;
   const size_t plane = (size_t)Dlo * d1 * Dr;      // one s2-plane
@@ -626,6 +863,8 @@ int mpsk_transfer_left(mpsk_ctx* c, const mpsk_mposlice* H, int W, int d, int Dl
   int Wl = W, Wr = W;
   if (H) { Wl = H->Wl; Wr = H->Wr; d = H->d; }
   REQUIRE(Wl > 0 && d > 0 && Dl > 0 && Dr > 0 && Dlb > 0 && Drb > 0, "dimensions must be positive");
+  if ((H ? H->dtype : c->dtype) == MPSK_C128)
+    return transfer_left_c128(c, H, W, d, Dl, Dr, Dlb, Drb, (const double*)GLin, (const double*)A, (const double*)Ab, (double*)GLout);
   const size_t slab = (size_t)Dlb * d * Dr;
   if (int rc = ensure_ws(c, sizeof(double) * slab * (Wl + (H ? Wr : 0)))) return rc;
   double* T1 = (double*)c->ws;
@@ -652,6 +891,8 @@ int mpsk_transfer_right(mpsk_ctx* c, const mpsk_mposlice* H, int W, int d, int D
   int Wl = W, Wr = W;
   if (H) { Wl = H->Wl; Wr = H->Wr; d = H->d; }
   REQUIRE(Wl > 0 && d > 0 && Dl > 0 && Dr > 0 && Dlb > 0 && Drb > 0, "dimensions must be positive");
+  if ((H ? H->dtype : c->dtype) == MPSK_C128)
+    return transfer_right_c128(c, H, W, d, Dl, Dr, Dlb, Drb, (const double*)A, (const double*)Ab, (const double*)GRin, (double*)GRout);
   const size_t plane = (size_t)Dr * Dlb;   // one physical index
   const size_t slab = plane * d;
   if (int rc = ensure_ws(c, sizeof(double) * slab * (Wr + (H ? Wl : 0)))) return rc;

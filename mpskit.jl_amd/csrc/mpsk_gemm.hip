@@ -80,19 +80,23 @@ template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
       }
     }
   }
-  __device__ inline void store(double* __restrict__ lds, int tid) const {
+  // jf (complex kernels only): every 16-B vector is one complex number (re, im) -- along M for an MN-contiguous
+  // operand, along K for a K-contiguous one -- and is multiplied by i (jf = 1) or -i (jf = 2) on its way into LDS
+  __device__ inline void store(double* __restrict__ lds, int tid, int jf = 0) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int v = tid + i * NTHREADS;
       int mn, k;
       if (KCONTIG) { k = (v % (BK / 2)) * 2; mn = v / (BK / 2); }
       else         { mn = (v % (BMN / 2)) * 2; k = v / (BMN / 2); }
+      d2 w = r[i];
+      if (jf == 1) w = d2{-w.y, w.x};
+      else if (jf == 2) w = d2{w.y, -w.x};
       if (KCONTIG) {   // (k, k+1), k even, share one 16-B slot of the swizzled row; odd rows swap the halves
-        d2 v = r[i];
-        if (mn & 1) v = d2{v.y, v.x};
-        *reinterpret_cast<d2*>(&lds[Img::idx(mn, k) & ~1]) = v;
+        if (mn & 1) w = d2{w.y, w.x};
+        *reinterpret_cast<d2*>(&lds[Img::idx(mn, k) & ~1]) = w;
       } else {
-        *reinterpret_cast<d2*>(&lds[Img::idx(mn, k)]) = r[i];
+        *reinterpret_cast<d2*>(&lds[Img::idx(mn, k)]) = w;
       }
     }
   }
@@ -122,7 +126,7 @@ __device__ __forceinline__ double row_rot(double x) {
   return __hiloint2double(hi, lo);
 }
 
-template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false>
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false, bool CJ = false>
 __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double* __restrict__ Ab,
                                                 const double* __restrict__ Bb, int z, int m0, int n0, int ktb, int kte,
                                                 d4 (&acc)[BM / 32][BN / 32], double* smem) {
@@ -150,7 +154,7 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
   auto offB = [&](int sg) -> int64_t { if constexpr (ZS) return zsb[sg]; else return g.segB[sg]; };
   la.load(Ab + offA(seg), g.lda, m0, kt * BK, g.M, g.K, tid);
   lb.load(Bb + offB(seg), g.ldb, n0, kt * BK, g.N, g.K, tid);
-  la.store(sA, tid);
+  la.store(sA, tid, CJ ? (int)g.segJ[seg] : 0);
   lb.store(sB, tid);
   __syncthreads();
   for (int t = ktb; t < kte; ++t) {
@@ -214,7 +218,7 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
 #endif
     }
     if (t + 1 < kte) {
-      la.store(sA + (cur ^ 1) * IA::SIZE, tid);
+      la.store(sA + (cur ^ 1) * IA::SIZE, tid, CJ ? (int)g.segJ[seg2] : 0);
       lb.store(sB + (cur ^ 1) * IB::SIZE, tid);
     }
     __syncthreads();
@@ -261,7 +265,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& g, int t, int tilesM
 }
 
 // epilogue: lane holds C[m = .. + fr][n = .. + fq + 4*reg]
-template <int BM, int BN, bool ALIGNED>
+template <int BM, int BN, bool ALIGNED, bool CJ = false>
 __device__ __forceinline__ void gemm_store_c(const GemmArgs& g, double* __restrict__ Cb, int z, int m0, int n0,
                                              const d4 (&acc)[BM / 32][BN / 32]) {
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
@@ -277,9 +281,10 @@ __device__ __forceinline__ void gemm_store_c(const GemmArgs& g, double* __restri
       for (int rg = 0; rg < 4; ++rg) {
         const int n = n0 + wn * WTN + j * 16 + fq + 4 * rg;
         if (ALIGNED || (m < g.M && n < g.N)) {
+          const int64_t mo = CJ ? (int64_t)m * g.c_rs : (int64_t)m;
           double* p = (g.tabC2 != nullptr && n >= g.splitN)
-                          ? g.C + g.tabC2[z] + m + (int64_t)(n - g.splitN) * g.ldc
-                          : Cb + m + (int64_t)n * g.ldc;
+                          ? g.C + g.tabC2[z] + mo + (int64_t)(n - g.splitN) * g.ldc
+                          : Cb + mo + (int64_t)n * g.ldc;
           double v = alpha * acc[i][j][rg];
           if (beta != 0.0) v += beta * (*p);
           *p = v;
@@ -304,7 +309,7 @@ __device__ __forceinline__ void gemm_store_ws(double alpha, double* __restrict__
         slot[(wm * WTM + i * 16 + fr) + (wn * WTN + j * 16 + fq + 4 * rg) * BM] = alpha * acc[i][j][rg];
 }
 
-template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false>
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false, bool CJ = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // XCD-aware tile mapping: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
@@ -329,8 +334,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 #pragma unroll
     for (int j = 0; j < BN / 32; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
   const int nt = ((g.K + BK - 1) / BK) * g.nseg;
-  gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS>(g, Ab, Bb, z, m0, n0, 0, nt, acc, smem);
-  gemm_store_c<BM, BN, ALIGNED>(g, Cb, z, m0, n0, acc);
+  gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS, CJ>(g, Ab, Bb, z, m0, n0, 0, nt, acc, smem);
+  gemm_store_c<BM, BN, ALIGNED, CJ>(g, Cb, z, m0, n0, acc);
 }
 
 // ---- stream-K: equal shares of the flattened (tile, k-tile) work list ---------------------------
@@ -463,6 +468,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_zs_f64_kernel(GemmArgs g
   gemm_body<BM, BN, false, false, ALIGNED, true>(g);
 }
 
+// complex128 family (A / C rows interleaved re-im, B planar; GemmArgs::segJ / c_rs): same body with the J-aware loader
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void cgemm_f64_kernel(GemmArgs g) {
+  gemm_body<BM, BN, TA, TB, ALIGNED, false, true>(g);
+}
+
 // ---- event profile of the tagged (matvec) launches ---------------------------------------------
 struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned, sk, zs; };
 // The profile is process-wide (every ctx's tagged launches land in one list); the list is mutex-protected because
@@ -541,6 +552,11 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   ProfRec r;
   r.flops = 2.0 * g.M * g.N * (double)g.K * g.nseg * g.batch; r.bm = BM; r.bn = BN; r.aligned = ALIGNED; r.sk = 0; r.zs = zs;
   hipError_t e = hipSuccess;
+  if (g.cplx) {             // complex128 family: J-aware A loader, optional row-strided C; data-parallel tiles only
+    if (zs || g.sk_units > 0) return hipErrorInvalidValue;
+    static std::atomic<uint64_t> c0{0};
+    return launch_one(cgemm_f64_kernel<BM, BN, TA, TB, ALIGNED>, c0, grid, smem, g, s, false, &r);
+  }
   if constexpr ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) {
     if (g.sk_units > 0) {   // stream-K launch: equal k-tile shares + fixed-order fixup of split tiles
       const int KT = ((g.K + BK - 1) / BK) * g.nseg;
@@ -648,7 +664,9 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   choose_tile(g.M, g.N, g.batch, &bm, &bn);
   g.sk_units = 0;
   g.sk_ws = nullptr;
+  if (g.cplx && g.c_rs == 0) g.c_rs = 1;
   if (g_force_bm.load()) { bm = g_force_bm.load(); bn = g_force_bn.load(); }
+  else if (g.cplx) { /* no split-K / stream-K: the complex epilogue lives in gemm_store_c only */ }
   else {
     const int KT = ((g.K + BK - 1) / BK) * g.nseg;
     const int64_t Tb = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;

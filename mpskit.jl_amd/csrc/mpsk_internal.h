@@ -54,6 +54,15 @@ struct GemmArgs {
   // A + tabA/bsA offset + zsegA[z * nseg + i] (override segA / segB when set; nseg is uniform over the batches)
   const int64_t* zsegA;
   const int64_t* zsegB;
+  // complex128 operands carried as REAL matrices with (re, im) interleaved along the first (row) index of the A operand
+  // and of C ("half-embedded" real view of TensorKit's interleaved complex storage), B planar (separate re / im planes):
+  //   C_half = A_half Br + (J A_half) Bi,   J (re, im) = (-im, re)  -- the multiplication by i on a row pair.
+  // segJ[i]: what the A loader applies to K-segment i: 0 nothing, 1 J, 2 -J.  cplx selects the kernel family with that
+  // loader (the real kernels do not carry the test).  c_rs: row stride of C (1, or 2 to write one plane of an interleaved
+  // complex result: transfer_left's Ab^H T2).
+  signed char segJ[MAXSEG];
+  int cplx;
+  int c_rs;
   int tag;                   // 1: matvec-stage launch (own kernel symbol + event profile)
   int tabs_even;             // caller guarantees every tabA/tabB entry is even (16-B aligned operands)
 };
@@ -70,13 +79,14 @@ std::string gemm_prof_summary();
 // ---- slab mixing:  out_slab[o][r,c] = sum_t coef[t] * in_slab[src[t]][r,c]  --------------------
 // A "slab" is an R x C column-major matrix view (ld, base offset) inside a larger tensor.  This
 // is the (w,s) -> (v,t) application of the small MPO tensor between the two big GEMMs.
-struct MixTerm { int32_t out, in; double coef; };
+struct MixTerm { int32_t out, in; double coef; double coef_im = 0.0; };
 
 struct MixPlan {          // device-resident CSR: terms grouped by output slab
   int n_out = 0, n_in = 0;
   int32_t* d_rowptr = nullptr;   // [n_out+1]
   int32_t* d_src = nullptr;      // [nnz]
   double* d_coef = nullptr;      // [nnz]
+  double* d_coef_im = nullptr;   // [nnz] imaginary parts (complex plans: slabs hold (re, im) row pairs), else null
   int nnz = 0;
   int max_terms = 0;
 };
@@ -89,6 +99,10 @@ void mix_plan_destroy(MixPlan* plan);
 struct SlabIndex { int n0, n1; int64_t s0, s1, s2; int64_t ld; };
 hipError_t mix_apply(const MixPlan& plan, const double* in, SlabIndex iin, double* out, SlabIndex iout,
                      int R, int C, hipStream_t s);
+// dst[r * drs + c * dcs] = src[r * srs + c * scs]   (R x C elements, arbitrary strides): interleaved <-> planar complex,
+// extraction of the real / imaginary planes of an embedded tensor
+hipError_t copy_strided(const double* src, int64_t srs, int64_t scs, double* dst, int64_t drs, int64_t dcs, int64_t R,
+                        int64_t C, hipStream_t s);
 
 // ---- vector kernels ---------------------------------------------------------------------------
 // xs: HOST array of k device pointers; d_out / d_coefs: device [k]; d_partial: device scratch

@@ -22,6 +22,7 @@ template <bool VEC2>
 __global__ __launch_bounds__(256) void mix_kernel(const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ src,
                                                   const double* __restrict__ coef,
+                                                  const double* __restrict__ coef_im,
                                                   const double* __restrict__ in, SlabIndex iin,
                                                   double* __restrict__ out, SlabIndex iout, int R, int C) {
   const int o = blockIdx.y;
@@ -34,12 +35,22 @@ __global__ __launch_bounds__(256) void mix_kernel(const int32_t* __restrict__ ro
          e += (int64_t)gridDim.x * blockDim.x) {
       int r = (int)(e % R2) * 2, c = (int)(e / R2);
       d2 acc = {0.0, 0.0};
-      for (int t = t0; t < t1; ++t) {
-        const double* ip = in + slab_off(iin, src[t]) + r + (int64_t)c * iin.ld;
-        d2 v = *reinterpret_cast<const d2*>(ip);
-        double cf = coef[t];
-        acc.x += cf * v.x;
-        acc.y += cf * v.y;
+      if (coef_im) {          // complex plan: every 16-B vector is one complex number (re, im)
+        for (int t = t0; t < t1; ++t) {
+          const double* ip = in + slab_off(iin, src[t]) + r + (int64_t)c * iin.ld;
+          d2 v = *reinterpret_cast<const d2*>(ip);
+          const double cr = coef[t], ci = coef_im[t];
+          acc.x += cr * v.x - ci * v.y;
+          acc.y += cr * v.y + ci * v.x;
+        }
+      } else {
+        for (int t = t0; t < t1; ++t) {
+          const double* ip = in + slab_off(iin, src[t]) + r + (int64_t)c * iin.ld;
+          d2 v = *reinterpret_cast<const d2*>(ip);
+          double cf = coef[t];
+          acc.x += cf * v.x;
+          acc.y += cf * v.y;
+        }
       }
       *reinterpret_cast<d2*>(op + r + (int64_t)c * iout.ld) = acc;
     }
@@ -58,12 +69,13 @@ __global__ __launch_bounds__(256) void mix_kernel(const int32_t* __restrict__ ro
 
 hipError_t mix_plan_create(const std::vector<MixTerm>& terms, int n_out, int n_in, MixPlan* plan) {
   std::vector<int32_t> rowptr(n_out + 1, 0), src(terms.size());
-  std::vector<double> coef(terms.size());
-  for (auto& t : terms) rowptr[t.out + 1]++;
+  std::vector<double> coef(terms.size()), coef_im(terms.size());
+  bool cplx = false;
+  for (auto& t : terms) { rowptr[t.out + 1]++; if (t.coef_im != 0.0) cplx = true; }
   int mx = 0;
   for (int i = 0; i < n_out; ++i) { if (rowptr[i + 1] > mx) mx = rowptr[i + 1]; rowptr[i + 1] += rowptr[i]; }
   std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
-  for (auto& t : terms) { int p = fill[t.out]++; src[p] = t.in; coef[p] = t.coef; }
+  for (auto& t : terms) { int p = fill[t.out]++; src[p] = t.in; coef[p] = t.coef; coef_im[p] = t.coef_im; }
   plan->n_out = n_out; plan->n_in = n_in; plan->nnz = (int)terms.size(); plan->max_terms = mx;
   hipError_t e;
   if ((e = hipMalloc(&plan->d_rowptr, sizeof(int32_t) * (n_out + 1))) != hipSuccess) return e;
@@ -74,6 +86,10 @@ hipError_t mix_plan_create(const std::vector<MixTerm>& terms, int n_out, int n_i
   if (terms.size()) {
     if ((e = hipMemcpy(plan->d_src, src.data(), sizeof(int32_t) * terms.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(plan->d_coef, coef.data(), sizeof(double) * terms.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if (cplx) {
+      if ((e = hipMalloc(&plan->d_coef_im, sizeof(double) * nz)) != hipSuccess) return e;
+      if ((e = hipMemcpy(plan->d_coef_im, coef_im.data(), sizeof(double) * terms.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    }
   }
   return hipSuccess;
 }
@@ -82,6 +98,7 @@ void mix_plan_destroy(MixPlan* plan) {
   if (plan->d_rowptr) (void)hipFree(plan->d_rowptr);
   if (plan->d_src) (void)hipFree(plan->d_src);
   if (plan->d_coef) (void)hipFree(plan->d_coef);
+  if (plan->d_coef_im) (void)hipFree(plan->d_coef_im);
   *plan = MixPlan();
 }
 
@@ -91,6 +108,7 @@ hipError_t mix_apply(const MixPlan& plan, const double* in, SlabIndex iin, doubl
   bool vec2 = (R % 2 == 0) && (iin.ld % 2 == 0) && (iout.ld % 2 == 0) && (iin.s0 % 2 == 0) &&
               (iin.s1 % 2 == 0) && (iin.s2 % 2 == 0) && (iout.s0 % 2 == 0) && (iout.s1 % 2 == 0) &&
               (iout.s2 % 2 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (plan.d_coef_im && !vec2) return hipErrorInvalidValue;   // complex slabs are (re, im) row pairs: always even / aligned
   int64_t work = vec2 ? (int64_t)(R / 2) * C : (int64_t)R * C;
   int bx = (int)((work + 255) / 256);
   int cap = (2048 + plan.n_out - 1) / plan.n_out;
@@ -99,11 +117,29 @@ hipError_t mix_apply(const MixPlan& plan, const double* in, SlabIndex iin, doubl
   if (bx < 1) bx = 1;
   dim3 grid(bx, plan.n_out, 1);
   if (vec2)
-    hipLaunchKernelGGL(mix_kernel<true>, grid, dim3(256), 0, s, plan.d_rowptr, plan.d_src, plan.d_coef, in,
+    hipLaunchKernelGGL(mix_kernel<true>, grid, dim3(256), 0, s, plan.d_rowptr, plan.d_src, plan.d_coef, plan.d_coef_im, in,
                        iin, out, iout, R, C);
   else
-    hipLaunchKernelGGL(mix_kernel<false>, grid, dim3(256), 0, s, plan.d_rowptr, plan.d_src, plan.d_coef, in,
+    hipLaunchKernelGGL(mix_kernel<false>, grid, dim3(256), 0, s, plan.d_rowptr, plan.d_src, plan.d_coef, plan.d_coef_im, in,
                        iin, out, iout, R, C);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restrict__ src, int64_t srs, int64_t scs,
+                                                           double* __restrict__ dst, int64_t drs, int64_t dcs, int64_t R,
+                                                           int64_t C) {
+  const int64_t total = R * C;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e % R, c = e / R;
+    dst[r * drs + c * dcs] = src[r * srs + c * scs];
+  }
+}
+hipError_t copy_strided(const double* src, int64_t srs, int64_t scs, double* dst, int64_t drs, int64_t dcs, int64_t R,
+                        int64_t C, hipStream_t s) {
+  if (R <= 0 || C <= 0) return hipSuccess;
+  int64_t nb = (R * C + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, srs, scs, dst, drs, dcs, R, C);
   return hipGetLastError();
 }
 

@@ -1,0 +1,136 @@
+"""Native complex128 (MPSK_C128, the reference's default scalar type, defaults.jl:18) for the matvec / transfer family:
+interleaved complex128 tensors through the C ABI against the oracle's complex arithmetic (derivatives.jl:77-193,
+transfer.jl:18-126 with complex tensors; conj(Ab) on the bra).  Bar: 1e-12 relative."""
+import numpy as np
+import pytest
+
+import mpskit_oracle as mo
+
+pytestmark = pytest.mark.gpu
+RTOL = 4e-13
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def crand(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+def rand_cslice(rng, odim, d, chis, density=0.6, scal_prob=0.3):
+    blocks = {(0, 0): 1.0, (odim - 1, odim - 1): 1.0}
+    for i in range(odim):
+        for j in range(i, odim):
+            if (i, j) in blocks:
+                continue
+            if rng.random() < density:
+                if chis[i] == chis[j] and rng.random() < scal_prob:
+                    blocks[(i, j)] = complex(rng.standard_normal(), rng.standard_normal())
+                else:
+                    blocks[(i, j)] = crand(rng, chis[i], d, d, chis[j])
+    return mo.SparseMPOSlice(odim, d, chis, chis, blocks)
+
+
+def dev_cslice(be, s):
+    return be.mposlice(s.odim, s.d, s.chil, s.chir, dict(s.Os), cplx=True)
+
+
+CASES = [
+    (4, 4, 2, [1, 1, 1]),
+    (16, 16, 2, [1, 1, 1, 1, 1]),
+    (7, 13, 3, [1, 2, 1]),           # ragged, odd dims (unaligned kernels), chi > 1
+    (64, 64, 2, [1, 1, 1, 1, 1]),
+    (33, 65, 2, [1, 3, 2, 1]),
+    (128, 96, 4, [1, 1, 1, 1, 1, 1]),
+    (256, 256, 2, [1, 1, 1, 1, 1]),
+    (1, 2, 2, [1, 1, 1]),            # chain edge
+]
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", CASES)
+def test_dAC_dC_complex(be, Dl, Dr, d, chis):
+    rng = np.random.default_rng(1000 + 7 * Dl + Dr)
+    s = rand_cslice(rng, len(chis), d, chis)
+    GL = [crand(rng, Dl, c, Dl) for c in chis]
+    GR = [crand(rng, Dr, c, Dr) for c in chis]
+    x = crand(rng, Dl, d, Dr)
+    H, dGL, dGR = dev_cslice(be, s), be.upload_env_c(GL), be.upload_env_c(GR)
+    ref = mo.dAC(x, s, GL, GR)
+    y = be.download_c(be.dAC(H, dGL, dGR, be.upload_c(x)))
+    assert relerr(y, ref) < RTOL * max(Dl, Dr)
+    # prepared operator: planar right environment built once, applied twice
+    hac = be.hac_create(H, dGL, dGR)
+    assert hac.info()["mode"] == 2
+    for _ in range(2):
+        x = crand(rng, Dl, d, Dr)
+        assert relerr(be.download_c(hac.apply(be.upload_c(x))), mo.dAC(x, s, GL, GR)) < RTOL * max(Dl, Dr)
+    # dC with the same environments
+    c = crand(rng, Dl, Dr)
+    yc = be.download_c(be.dC(dGL, dGR, be.upload_c(c), cplx=True))
+    assert relerr(yc, mo.dC(c, GL, GR)) < RTOL * max(Dl, Dr)
+    # a complex slice whose entries happen to be real == the real slice applied to complex tensors
+    sr = mo.SparseMPOSlice(len(chis), d, chis, chis, {k: (np.real(v) if np.isscalar(v) else np.real(v)) for k, v in s.Os.items()})
+    yr = be.download_c(be.dAC(dev_cslice(be, sr), dGL, dGR, be.upload_c(x)))
+    assert relerr(yr, mo.dAC(x, sr, GL, GR)) < RTOL * max(Dl, Dr)
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", [c for c in CASES if c[0] <= 128])
+def test_dAC2_complex(be, Dl, Dr, d, chis):
+    rng = np.random.default_rng(2000 + Dl)
+    s1, s2 = rand_cslice(rng, len(chis), d, chis), rand_cslice(rng, len(chis), d, chis)
+    GL = [crand(rng, Dl, c, Dl) for c in chis]
+    GR = [crand(rng, Dr, c, Dr) for c in chis]
+    x2 = crand(rng, Dl, d, Dr, d)
+    y = be.download_c(be.dAC2(dev_cslice(be, s1), dev_cslice(be, s2), be.upload_env_c(GL), be.upload_env_c(GR), be.upload_c(x2)))
+    assert relerr(y, mo.dAC2(x2, s1, s2, GL, GR)) < RTOL * max(Dl, Dr)
+
+
+@pytest.mark.parametrize("Dl,Dr,d,chis", CASES)
+def test_transfer_left_right_complex(be, Dl, Dr, d, chis):
+    """transfer.jl:105-110,166-259 with complex A, Abar (conjugated on the bra) and environments; bra and ket bond
+    dimensions differ (Dlb = Dl + 1 ...) as in the excitation / overlap transfers."""
+    rng = np.random.default_rng(3000 + Dl * 3 + Dr)
+    s = rand_cslice(rng, len(chis), d, chis)
+    Dlb, Drb = Dl + 1, Dr + 2
+    A, Ab = crand(rng, Dl, d, Dr), crand(rng, Dlb, d, Drb)
+    GLin = [crand(rng, Dlb, c, Dl) for c in chis]
+    GRin = [crand(rng, Dr, c, Drb) for c in chis]
+    H = dev_cslice(be, s)
+    dA, dAb = be.upload_c(A), be.upload_c(Ab)
+    tl = be.download_env_c(be.transfer_left(H, be.upload_env_c(GLin), dA, dAb), chis)
+    for a, b in zip(tl, mo.transfer_left(GLin, s, A, Ab)):
+        assert relerr(a, b) < RTOL * max(Dl, Dr) * 2
+    tr = be.download_env_c(be.transfer_right(H, be.upload_env_c(GRin), dA, dAb), chis)
+    for a, b in zip(tr, mo.transfer_right(GRin, s, A, Ab)):
+        assert relerr(a, b) < RTOL * max(Dl, Dr) * 2
+    # pass-through legs (H = NULL): W independent slabs  (transfer.jl:18-45,66-75)
+    vl = [crand(rng, Dlb, 1, Dl) for _ in range(2)]
+    vr = [crand(rng, Dr, 1, Drb) for _ in range(2)]
+    pl = be.download_env_c(be.transfer_left(None, be.upload_env_c(vl), dA, dAb, cplx=True), [1, 1])
+    pr = be.download_env_c(be.transfer_right(None, be.upload_env_c(vr), dA, dAb, cplx=True), [1, 1])
+    for k in range(2):
+        assert relerr(pl[k][:, 0, :], mo.transfer_left_bond(vl[k][:, 0, :], A, Ab)) < RTOL * max(Dl, Dr) * 2
+        assert relerr(pr[k][:, 0, :], mo.transfer_right_bond(vr[k][:, 0, :], A, Ab)) < RTOL * max(Dl, Dr) * 2
+
+
+def test_complex_effective_hamiltonian_is_hermitian(be):
+    """Hermitian MPO + Hermitian-paired environments -> <u, H v> = conj(<v, H u>) (size-independent identity at D = 512)."""
+    rng = np.random.default_rng(9)
+    D, d = 512, 2
+    Sz = np.diag([0.5, -0.5]).astype(complex)
+    Sp = np.array([[0, 1], [0, 0]], dtype=complex)
+    Sy = np.array([[0, -0.5j], [0.5j, 0]])
+    blocks = {(0, 0): 1.0, (3, 3): 1.0, (0, 1): Sz[None, :, :, None], (1, 3): Sz[None, :, :, None],
+              (0, 2): Sy[None, :, :, None], (2, 3): Sy[None, :, :, None], (0, 3): (0.3 * Sz + 0.2 * (Sp + Sp.T))[None, :, :, None]}
+    H = be.mposlice(4, d, [1] * 4, [1] * 4, blocks, cplx=True)
+    herm = lambda m: m + np.conj(np.transpose(m, (0, 2, 1)))
+    gl = herm(crand(rng, 4, D, D))
+    gr = herm(crand(rng, 4, D, D))
+    GL = be.upload_env_c([m[:, None, :] for m in gl])
+    GR = be.upload_env_c([m[:, None, :] for m in gr])
+    u, v = crand(rng, D, d, D), crand(rng, D, d, D)
+    hac = be.hac_create(H, GL, GR)
+    Hu, Hv = be.download_c(hac.apply(be.upload_c(u))), be.download_c(hac.apply(be.upload_c(v)))
+    a, b = np.vdot(u, Hv), np.vdot(Hu, v)
+    assert abs(a - b) < 1e-11 * abs(a) * D
