@@ -69,10 +69,20 @@ def updatetol(tol_min, tol_max, factor, it, eps):  # dynamictols.jl:50-53
 
 
 def fixedpoint(be, A, x0, alg: Arnoldi, ws=None, first_image=None):
-    """fixedpoint(A, x0, :SR, alg)  (fixedpoint.jl:19-30); non-convergence only warns."""
+    """fixedpoint(A, x0, :SR, alg)  (fixedpoint.jl:19-30); non-convergence only warns.
+    A native complex operator (cplx.HalfEmbeddedOp) given an EMBEDDED start tensor is solved on the half-embedded
+    (interleaved complex) vectors: encode once, iterate, decode once."""
+    wrap = hasattr(A, "is_half") and not A.is_half(x0)
+    if wrap:
+        x0 = A.encode(x0)
+        fi, first_image = first_image, (None if first_image is None else be.empty(*x0.shape))
     lam, vec, nmv, res = krylov.eigsolve_sr(be, A, x0, tol=alg.tol, krylovdim=alg.krylovdim,
                                             maxiter=alg.maxiter, fixed_matvecs=alg.fixed_matvecs, ws=ws,
                                             first_image=first_image)
+    if wrap:
+        vec = A.decode(vec)
+        if fi is not None:
+            A.decode(first_image, out=fi)
     return lam, vec
 
 
@@ -182,7 +192,7 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
         x0 = ac_old if enc is None else enc(ac_old)
         # the eigensolver's first matvec is H_AC (AC_old / |AC_old|): exactly the vector calc_galerkin of the old
         # tensor normalises (toolbox.jl:18), so it is captured instead of applying H_AC to AC_old a second time
-        g = be.empty(*ac_old.shape)
+        g = be.empty(*x0.shape)
         _, vec = fixedpoint(be, h, x0, eigalg, ws, first_image=g)
         if enc is not None:
             vec, g = h.decode(vec), h.decode(g)
@@ -377,12 +387,22 @@ def integrate(be, f, y0, t, dt, alg, ws=None, cplx=False):
     Embedded complex states (cplx.py): any complex dt;  exp(z f) with z = -im*dt = zr + i zi is the exponential of
     the real generator  x -> zr f(x) + zi (i f(x))  on the embedded tensors (general Arnoldi)."""
     z = -1j * complex(dt)
+    enc = getattr(f, "encode", None)
+    if enc is not None and cplx:
+        # native complex128 operator (cplx.HalfEmbeddedOp): iterate on the half-embedded (= interleaved complex) vector
+        yh = _integrate_embedded(be, f.apply_half, enc(y0), z, alg, ws)
+        return f.decode(yh)
     if not cplx:
         if abs(z.imag) > 0.0:
             raise NotImplementedError("real-time evolution of a REAL state leaves the reals: build the state from "
                                       "complex tensors (FiniteMPS(..., dtype=complex)) or pass dt = -1j*tau")
         y, _ = krylov.exponentiate(be, f, z.real, y0, tol=alg.tol, krylovdim=alg.krylovdim, maxiter=alg.maxiter, ws=ws)
         return y
+    return _integrate_embedded(be, f, y0, z, alg, ws)
+
+
+def _integrate_embedded(be, f, y0, z, alg, ws):
+    """exp(z f) y0 on (half-)embedded complex tensors: multiplication by i is (I (x) J) on the interleaved row pairs."""
     if z.imag == 0.0:
         y, _ = krylov.exponentiate(be, f, z.real, y0, tol=alg.tol, krylovdim=alg.krylovdim, maxiter=alg.maxiter, ws=ws)
         return y

@@ -47,6 +47,103 @@ def structure_defect(E):
                np.abs(E[0::2, ..., 1::2] + E[1::2, ..., 0::2]).max(initial=0.0))
 
 
+class HalfEmbeddedOp:
+    """Effective Hamiltonian of an EMBEDDED complex state applied through the NATIVE complex128 kernels (MPSK_C128).
+
+    The state tensors and environments of a complex FiniteMPS / InfiniteMPS are stored embedded (module docstring);
+    inside a Krylov solve the iterate only needs ONE column of every 2x2 block -- E[:, ..., 2b] -- and that
+    "half-embedded" tensor (2 Dl, d, Dr) IS the interleaved complex128 tensor of the C ABI (include/mpsk.h).  So:
+      prepare (once per site visit): GLc / GRc = even columns of the embedded environment slabs (interleaved complex
+              environments), the complex twin of the real MPO slice, the prepared operator (mpsk_hac_create);
+      encode / decode (once per solve): embedded tensor <-> even columns;  decode rebuilds [h | J h];
+      apply: mpsk_hac_apply / mpsk_dC / mpsk_dAC2 on complex operands -- 4x the real flops instead of the 8x of the
+             embedded matvec, half the vector length in every Krylov vector operation.
+    `h(x)` with an embedded x encodes / decodes around the call, so callers that do not know the protocol still work;
+    solvers that do (dmrg_sweep, integrate) call encode once, iterate on half vectors, decode once."""
+
+    def __init__(self, be, kind, slices, GL_E: DTensor, GR_E: DTensor):
+        self.be, self.kind = be, kind
+        self.slices = [self._cslice(be, h) for h in slices]
+        W, Dlo2, Dl2 = GL_E.shape
+        Wr, Dr2, _ = GR_E.shape
+        self.Dlo, self.Dl, self.Dr = Dlo2 // 2, Dl2 // 2, Dr2 // 2
+        # even columns of every slab: (Dlo2 x W * Dl2) matrix -> (Dlo2 x W * Dl)
+        self.GLc = be.empty(W, Dlo2, self.Dl)
+        be.copy2d(Dlo2, W * self.Dl, GL_E.ptr, 2 * Dlo2, self.GLc.ptr, Dlo2)
+        self.GRc = be.empty(Wr, Dr2, self.Dr)
+        be.copy2d(Dr2, Wr * self.Dr, GR_E.ptr, 2 * Dr2, self.GRc.ptr, Dr2)
+        self._hac = be.hac_create(self.slices[0], self.GLc, self.GRc) if kind == "AC" else None
+        self._keep = (GL_E, GR_E)
+
+    @staticmethod
+    def _cslice(be, H):
+        c = getattr(H, "_cslice", None)
+        if c is None:
+            c = be.mposlice(H.odim, H.d, H.chil, H.chir, H.blocks, cplx=True)
+            H._cslice = c
+        return c
+
+    # ---- layout: the doubled ket bond is the 3rd index (AC, AC2) or the 2nd (C); AC2 has a trailing physical index
+    def _geom(self, shape):
+        if self.kind == "C":
+            return shape[0], shape[1], 1
+        if self.kind == "AC":
+            return shape[0] * shape[1], shape[2], 1
+        return shape[0] * shape[1], shape[2], shape[3]
+
+    def _half_shape(self, shape):
+        k = 1 if self.kind == "C" else 2
+        return tuple(shape[:k]) + (shape[k] // 2,) + tuple(shape[k + 1:])
+
+    def _full_shape(self, shape):
+        k = 1 if self.kind == "C" else 2
+        return tuple(shape[:k]) + (shape[k] * 2,) + tuple(shape[k + 1:])
+
+    def is_half(self, x: DTensor):
+        k = 1 if self.kind == "C" else 2
+        return x.shape[k] == self.Dr
+
+    def encode(self, x: DTensor, out: DTensor = None):
+        be = self.be
+        rows, n2, tail = self._geom(x.shape)
+        out = be.empty(*self._half_shape(x.shape)) if out is None else out
+        n = n2 // 2
+        for j in range(tail):
+            be.copy2d(rows, n, x.ptr + 8 * j * rows * n2, 2 * rows, out.ptr + 8 * j * rows * n, rows)
+        return out
+
+    def decode(self, xh: DTensor, out: DTensor = None):
+        be = self.be
+        full = self._full_shape(xh.shape)
+        rows, n2, tail = self._geom(full)
+        out = be.empty(*full) if out is None else out
+        n = n2 // 2
+        jx = be.times_i(xh)                              # J x: (re, im) -> (-im, re) on every row pair
+        for j in range(tail):
+            be.copy2d(rows, n, xh.ptr + 8 * j * rows * n, rows, out.ptr + 8 * j * rows * n2, 2 * rows)
+            be.copy2d(rows, n, jx.ptr + 8 * j * rows * n, rows, out.ptr + 8 * (j * rows * n2 + rows), 2 * rows)
+        return out
+
+    def apply_half(self, xh: DTensor, out: DTensor = None):
+        be = self.be
+        if self.kind == "AC":
+            return self._hac.apply(xh, out=out)
+        if self.kind == "C":
+            return be.dC(self.GLc, self.GRc, xh, out=out, cplx=True)
+        return be.dAC2(self.slices[0], self.slices[1], self.GLc, self.GRc, xh, out=out)
+
+    def __call__(self, x: DTensor, out: DTensor = None):
+        if self.is_half(x):
+            return self.apply_half(x, out)
+        y = self.decode(self.apply_half(self.encode(x)))
+        if out is not None:
+            self.be.axpby(1.0, y, 0.0, out)
+            return out
+        return y
+
+    __mul__ = __call__
+
+
 def times_i(be, x: DTensor, out: DTensor = None):
     """emb(i * z) = (I_Dl (x) J) . emb(z) with J = [[0, -1], [1, 0]] acting on the first (left bond) index:
     rows (2a, 2a+1) -> (-row 2a+1, row 2a)  (mpsk_vtimes_i)."""

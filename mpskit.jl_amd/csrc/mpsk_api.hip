@@ -409,6 +409,7 @@ extern "C" {
 // so a complex product is the real GEMM core with two K-segments (the second through the J-aware A loader, GemmArgs::segJ)
 // on a B operand split into planes -- 4x the real flops, the complex optimum; intermediates stay interleaved.
 static hipError_t cx_planes(const double* z, size_t n, double* re, double* im, hipStream_t s) {     // interleaved -> planar
+  if ((uintptr_t)z % 16 == 0) return deinterleave(z, (int64_t)n, re, im, s);
   hipError_t e = copy_strided(z, 2, 0, re, 1, 0, (int64_t)n, 1, s);
   if (e != hipSuccess) return e;
   return copy_strided(z + 1, 2, 0, im, 1, 0, (int64_t)n, 1, s);

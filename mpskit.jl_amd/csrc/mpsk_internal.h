@@ -101,6 +101,7 @@ hipError_t mix_apply(const MixPlan& plan, const double* in, SlabIndex iin, doubl
                      int R, int C, hipStream_t s);
 // dst[r * drs + c * dcs] = src[r * srs + c * scs]   (R x C elements, arbitrary strides): interleaved <-> planar complex,
 // extraction of the real / imaginary planes of an embedded tensor
+hipError_t deinterleave(const double* z, int64_t n, double* re, double* im, hipStream_t s);   // z 16-byte aligned
 hipError_t copy_strided(const double* src, int64_t srs, int64_t scs, double* dst, int64_t drs, int64_t dcs, int64_t R,
                         int64_t C, hipStream_t s);
 

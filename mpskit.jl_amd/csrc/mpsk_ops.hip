@@ -134,6 +134,23 @@ __global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restr
     dst[r * drs + c * dcs] = src[r * srs + c * scs];
   }
 }
+// interleaved complex (re, im, re, im, ...) -> two planes, one pass
+__global__ __launch_bounds__(256) void deinterleave_kernel(const d2* __restrict__ z, double* __restrict__ re,
+                                                           double* __restrict__ im, int64_t n) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const d2 v = z[e];
+    re[e] = v.x;
+    im[e] = v.y;
+  }
+}
+hipError_t deinterleave(const double* z, int64_t n, double* re, double* im, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)nb), dim3(256), 0, s, reinterpret_cast<const d2*>(z), re, im, n);
+  return hipGetLastError();
+}
+
 hipError_t copy_strided(const double* src, int64_t srs, int64_t scs, double* dst, int64_t drs, int64_t dcs, int64_t R,
                         int64_t C, hipStream_t s) {
   if (R <= 0 || C <= 0) return hipSuccess;

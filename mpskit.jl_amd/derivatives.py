@@ -68,9 +68,28 @@ def _is_lazy(H, envs):
     return hasattr(envs, "envs") and hasattr(H, "fs")
 
 
+NATIVE_CPLX_MIN_D = 384     # embedded bond dimension 2 D below which the embedded matvec wins (launch-bound regime:
+                            # profiles/r02_bench_cplx.log -- native 1.81x at D = 1024, 1.57x at 512, 0.76x at 256)
+
+
+def _native_cplx(psi, *envs_):
+    """complex (embedded) state on a backend with the MPSK_C128 kernels: apply through cplx.HalfEmbeddedOp when the
+    tensors are large enough for the halved flop count to matter."""
+    import os
+    if not (getattr(psi, "cplx", False) and hasattr(psi.be, "hac_create")):
+        return False
+    mode = os.environ.get("MPSK_NATIVE_CPLX", "auto")          # "0": always embedded, "1": always native (A/B switch)
+    if mode in ("0", "1"):
+        return mode == "1"
+    return all(e.shape[1] // 2 >= NATIVE_CPLX_MIN_D for e in envs_)
+
+
 def ddC(pos, psi, H, envs):  # ∂∂C  derivatives.jl:34-36
     if _is_lazy(H, envs):
         return _lazy(ddC, pos, psi, H, envs)
+    if _native_cplx(psi, envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi)):
+        from .cplx import HalfEmbeddedOp
+        return HalfEmbeddedOp(psi.be, "C", [], envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi))
     return MPO_ddC(psi.be, envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi))
 
 
@@ -81,6 +100,9 @@ def ddAC(pos, psi, H, envs):  # ∂∂AC  derivatives.jl:44-46
         from .excitations import Proj_ddAC
         return Proj_ddAC(psi.be, envs.vector(pos, psi))
     opp = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
+    if _native_cplx(psi, envs.leftenv(pos, psi), envs.rightenv(pos, psi)):
+        from .cplx import HalfEmbeddedOp
+        return HalfEmbeddedOp(psi.be, "AC", [opp], envs.leftenv(pos, psi), envs.rightenv(pos, psi))
     return MPO_ddAC(psi.be, opp, envs.leftenv(pos, psi), envs.rightenv(pos, psi))
 
 
@@ -89,4 +111,7 @@ def ddAC2(pos, psi, H, envs):  # ∂∂AC2  derivatives.jl:55-58
         return _lazy(ddAC2, pos, psi, H, envs)
     o1 = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
     o2 = envs.opp[pos + 1] if hasattr(envs, "opp") else H[pos + 1]
+    if _native_cplx(psi, envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi)):
+        from .cplx import HalfEmbeddedOp
+        return HalfEmbeddedOp(psi.be, "AC2", [o1, o2], envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi))
     return MPO_ddAC2(psi.be, o1, o2, envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi))

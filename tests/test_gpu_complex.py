@@ -134,3 +134,25 @@ def test_complex_effective_hamiltonian_is_hermitian(be):
     Hu, Hv = be.download_c(hac.apply(be.upload_c(u))), be.download_c(hac.apply(be.upload_c(v)))
     a, b = np.vdot(u, Hv), np.vdot(Hu, v)
     assert abs(a - b) < 1e-11 * abs(a) * D
+
+
+@pytest.mark.parametrize("name", ["test_complex_states_realtime_tdvp_and_dmrg", "test_complex_two_site_algorithms",
+                                  "test_complex_infinite_mps_vumps"])
+def test_drivers_on_complex_states_through_the_native_operators(be, monkeypatch, name):
+    """The complex-state driver tests of test_gpu_algorithms.py (DMRG / TDVP / TDVP2 / DMRG2 / VUMPS vs the oracle's
+    complex arithmetic, dense expm, energy conservation) with the effective Hamiltonians FORCED through the native
+    MPSK_C128 kernels (cplx.HalfEmbeddedOp: encode -> Krylov on interleaved complex vectors -> decode); by default
+    tensors this small take the embedded path (derivatives.NATIVE_CPLX_MIN_D)."""
+    import test_gpu_algorithms as tga
+    from mpskit_jl_amd import cplx
+    monkeypatch.setenv("MPSK_NATIVE_CPLX", "1")
+    calls = {"n": 0}
+    orig = cplx.HalfEmbeddedOp.apply_half
+
+    def counted(self, xh, out=None):
+        calls["n"] += 1
+        return orig(self, xh, out)
+
+    monkeypatch.setattr(cplx.HalfEmbeddedOp, "apply_half", counted)
+    getattr(tga, name)(be)
+    assert calls["n"] > 10, "the native complex operator was not exercised"
