@@ -7,9 +7,12 @@
 A "step" is ONE full 1-site DMRG sweep (2L-2 site updates, dmrg.jl:33-38 of the reference) of
 the Heisenberg S=1/2 chain, L=100, D=1024, fp64, with a fixed Krylov budget of 8 matvecs per
 site, on a seeded synthetic uniform[0,1) random MPS that is already
-left-canonical and resident in HBM when the timed region starts.  N > 1: the bond index of the
-effective-Hamiltonian matvec is block-sharded over the ranks with one RCCL all-gather per matvec
-(strong scaling: the same chain on N GPUs).  Rank 0 prints ONE JSON line.
+left-canonical and resident in HBM when the timed region starts.  N > 1: the bond index is
+block-sharded over the ranks -- storage-sharded environments, one in-place RCCL all-gather per
+matvec, one all-reduce per left-environment update (strong scaling: the same chain on N GPUs).
+After the timed steps ONE extra sweep runs in converged-tolerance mode (`to_tolerance`), and at
+N = 1 the oracle's CPU restatement is timed on the host cores (`cpu_baseline`).  Rank 0 prints
+ONE JSON line.
 """
 import argparse
 import json
@@ -28,46 +31,90 @@ def flops_dAC(D, d, W):
     return 2 * W * D * D * d * D + 2 * W * W * d * d * D * D + 2 * W * D * d * D * D
 
 
-def cpu_baseline(L, D, d, budget_s=20.0):
-    """Oracle (NumPy/OpenBLAS restatement of the reference's per-block evaluation order) timed on
-    the host cores on a bounded sample: bulk-site updates (8 Krylov matvecs + galerkin matvec +
-    environment update + QRpos of the old and new AC), extrapolated to sweeps/s with the flop-model
-    weight of every site of the chain."""
+def kernel_source_hash():
+    """sha256 over the kernel sources a PMC traffic figure belongs to: a committed profiles/*pmc_traffic.json is only
+    attached to the bench line when it was collected on exactly these sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mpsk_gemm.hip", "mpsk_api.hip", "mpsk_ops.hip", "mpsk_internal.h"):
+        with open(os.path.join(ROOT, "mpskit.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(L, D, d, matvecs, budget_s=24.0, min_samples=3):
+    """The reference's CPU path timed on this box's host cores ("port": the oracle's restatement; the reference itself is
+    Julia and cannot run here).  One sample = one bulk-site update exactly as the reference performs it: `matvecs` Krylov
+    applications of H_AC + 1 more for calc_galerkin (toolbox.jl:18), each evaluated block by block (one pair of
+    contractions per non-zero MPO block, derivatives.jl:85-104), QRpos of the old and of the new AC (LAPACK geqrf +
+    orgqr through numpy), one transfer_left.  Every contraction is a plain BLAS dgemm on operands that are already in
+    GEMM layout (no permutes inside the timed region), OpenBLAS pinned to the physical cores -- so the number reflects
+    a BLAS-bound reference run, not NumPy overheads.  Extrapolated over the sweep with the D^3 flop model."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import mpskit_oracle as mo
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
     except Exception:
         cores = os.cpu_count() or 1
+    try:                                           # cgroup limit (the GPU box gives a CPU share)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    from threadpoolctl import threadpool_limits
     rng = np.random.default_rng(20240213)
-    H = mo.heisenberg_mpo(0.5)
-    slc = H[0]
+    slc = mo.heisenberg_mpo(0.5)[0]
     W = slc.odim
-    GL = [rng.random((D, 1, D)) for _ in range(W)]
-    GR = [rng.random((D, 1, D)) for _ in range(W)]
-    x = rng.random((D, d, D))
-    AL, _ = mo.leftorth(rng.random((D, d, D)))
+    keys = list(slc.keys())
+    # operands in GEMM layout: GL[i] as (D x D), x as (D x d D), GR[j] as (D x D); the d x d block acts on the middle index
+    GLm = [np.asfortranarray(rng.random((D, D))) for _ in range(W)]
+    GRm = [np.asfortranarray(rng.random((D, D))) for _ in range(W)]
+    Om = {k: (slc.Os[k] if np.isscalar(slc.Os[k]) else np.asarray(slc.Os[k]).reshape(d, d)) for k in keys}
+    x0 = np.asfortranarray(rng.random((D, d * D)))
+    flop_mv = len(keys) * (2.0 * D * D * d * D + 2.0 * D * d * D * D)          # what this evaluation order executes
+
+    def matvec(x):                                  # x: (D, d D) column-major  ==  x[a, (s, b)]
+        y = np.zeros((D * d, D), order="F")
+        for (i, j) in keys:
+            t1 = GLm[i] @ x                         # dgemm  D x D x dD      -> [p, (s, b)]
+            t3 = t1.reshape(D, d, D, order="F")
+            O = Om[(i, j)]
+            if np.isscalar(O):
+                t2 = O * t3
+            else:                                   # d x d physical block (O[t, s]): tiny, applied plane by plane
+                t2 = np.empty_like(t3)
+                for t in range(d):
+                    t2[:, t, :] = sum(O[t, s_] * t3[:, s_, :] for s_ in range(d))
+            y += t2.reshape(D * d, D, order="F") @ GRm[j]                       # dgemm  dD x D x D
+        return y.reshape(D, d * D, order="F")
 
     def site_update():
-        v = x
-        for _ in range(8 + 1):                 # 8 Krylov matvecs + 1 galerkin matvec
-            v = mo.dAC(v, slc, GL, GR)
+        v = x0
+        for _ in range(matvecs + 1):               # Krylov matvecs + the galerkin matvec
+            v = matvec(v)
             v = v / np.linalg.norm(v)
-        mo.leftorth(v)                         # QRpos of the old AC (galerkin projector)
-        al, _ = mo.leftorth(v)                 # QRpos of the new AC
-        mo.transfer_left(GL, slc, al, al)      # environment update
-    t0 = time.time()
-    site_update()
-    t_first = time.time() - t0
-    n = 1
-    while time.time() - t0 + t_first < budget_s and n < 8:
-        site_update()
-        n += 1
-    t_site = (time.time() - t0) / n
-    # flop-model weight of the whole sweep in units of a bulk site
-    dl = [1]                                   # bond dims min(d^i, D, d^(L-i))  (finitemps.jl:182-192)
+        a = v.reshape(D * d, D, order="F")
+        np.linalg.qr(a)                             # QRpos of the old AC (galerkin projector)
+        q, _ = np.linalg.qr(a)                      # QRpos of the new AC
+        al = q.reshape(D, d, D, order="F")
+        mo.transfer_left([g[:, None, :] for g in GLm], slc, al, al)             # environment update
+
+    with threadpool_limits(limits=int(cores)):
+        site_update()                               # warm-up (page faults, thread pool)
+        times = []
+        t_start = time.time()
+        while len(times) < min_samples or (time.time() - t_start < budget_s and len(times) < 12):
+            t0 = time.time()
+            site_update()
+            times.append(time.time() - t0)
+        t0 = time.time()
+        matvec(x0)
+        t_mv = time.time() - t0
+    t_site = float(np.median(times))
+    dl = [1]                                        # bond dims min(d^i, D, d^(L-i))  (finitemps.jl:182-192)
     for _ in range(1, L):
         dl.append(min(dl[-1] * d, D))
     dl.append(1)
@@ -76,11 +123,14 @@ def cpu_baseline(L, D, d, budget_s=20.0):
     bulk = 2.0 * D * D * D
     order = list(range(0, L - 1)) + list(range(L - 1, 0, -1))
     equiv = sum((dl[p] * dl[p] * dl[p + 1] + dl[p] * dl[p + 1] * dl[p + 1]) / bulk for p in order)
-    sweeps_per_s = 1.0 / (t_site * equiv)
-    return {"value": sweeps_per_s, "unit": "sweeps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} bulk-site updates at D={D} (8+1 dAC matvecs, 2 QRpos, 1 transfer_left; "
-                      f"{t_site:.2f} s each) of the oracle, extrapolated over the {len(order)} site updates of a "
-                      f"sweep by the D^3 flop model ({equiv:.1f} bulk-site equivalents)"}
+    return {"value": 1.0 / (t_site * equiv), "unit": "sweeps/s", "cores": int(cores), "kind": "port",
+            "operator_applications_per_site": matvecs + 1,
+            "matvec_gflops": round(flop_mv / t_mv / 1e9, 1),
+            "site_seconds": {"median": round(t_site, 3), "min": round(min(times), 3), "max": round(max(times), 3), "n": len(times)},
+            "sample": f"{len(times)} bulk-site updates at D={D} ({matvecs}+1 per-block dAC matvecs as plain dgemm calls on "
+                      f"GEMM-layout operands, 2 LAPACK QR, 1 transfer_left; OpenBLAS pinned to {int(cores)} threads) of the oracle's "
+                      f"restatement of the reference's evaluation order, median extrapolated over the {len(order)} site updates "
+                      f"of a sweep by the D^3 flop model ({equiv:.1f} bulk-site equivalents)"}
 
 
 def main():
@@ -92,6 +142,7 @@ def main():
     ap.add_argument("--D", type=int, default=1024)
     ap.add_argument("--matvecs", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tolerance-sweep", action="store_true", help="skip the extra converged-tolerance sweep")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded sweep (blocked vectors, storage-sharded environments, RCCL collectives) even with "
                          "one rank: exercises the N > 1 code path on a 1-GPU box")
@@ -165,12 +216,16 @@ def main():
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                     "launches": top["launches"], "avg_ms": round(top["avg_ms"], 5),
                     "flops_per_launch": top["flops"] / top["launches"], "traffic": None}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        # HBM bytes per launch from a separate rocprofv3 --pmc run of the north-star point (tools/dac_only.py: D = 1024,
-        # one GPU); for any other workload the counters were not collected -> null
+        # HBM-side bytes per launch of that kernel from the separate rocprofv3 --pmc passes of tools/pmc_quick.sh
+        # (FETCH_SIZE / WRITE_SIZE cannot share a pass with anything else; D = 1024 north-star point).  Attached only
+        # if the passes were taken on EXACTLY the kernel sources of this run (hash), else null.
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(pmc) and args.D == 1024 and world == 1:
             try:
-                roofline["traffic"] = json.load(open(pmc)).get(top["kernel"])
+                pj = json.load(open(pmc))
+                if pj.get("kernel_source_sha256_16") == kernel_source_hash() and top["kernel"] in pj:
+                    roofline["traffic"] = pj[top["kernel"]]
+                    roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/dac_only.py, same kernel sources)"
             except Exception:
                 pass
 
@@ -196,6 +251,32 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # converged-tolerance mode (SURVEY 8d / BASELINE.md section 3): ONE more sweep with the reference's default
+    # eigensolver, Arnoldi(tol = 1e-12, krylovdim = 30, eager) (defaults.jl:33) instead of the fixed budget
+    to_tol = None
+    if not args.no_tolerance_sweep:
+        nmv = {"n": 0}
+        orig_eig = krylov.eigsolve_sr
+
+        def counting(*a, **kw):
+            r = orig_eig(*a, **kw)
+            nmv["n"] += r[2]
+            return r
+
+        krylov.eigsolve_sr = counting
+        try:
+            barrier()
+            t0 = time.perf_counter()
+            eps_t = alg.dmrg_sweep(psi, H, envs, mk.Arnoldi(tol=1e-12, krylovdim=30, maxiter=1), ws)
+            barrier()
+            dt_t = time.perf_counter() - t0
+        finally:
+            krylov.eigsolve_sr = orig_eig
+        to_tol = {"sweeps_per_s": round(1.0 / dt_t, 4), "ms_per_sweep": round(dt_t * 1e3, 1),
+                  "eigensolver": "Arnoldi(tol=1e-12, krylovdim=30, eager), one Krylov cycle per site",
+                  "matvecs_per_site_mean": round(nmv["n"] / (2 * L - 2), 2),
+                  "max_galerkin": float(max(eps_t))}
+
     if rank == 0:
         out = {
             "metric": "DMRG sweeps/sec + ddAC matvec achieved-TFLOP/s, Heisenberg L=100 D=1024 fp64",
@@ -209,12 +290,14 @@ def main():
                        "all-gather per matvec, one all-reduce per left-environment update, gauge steps replicated"},
             "dAC_tflops": None if dac_tflops is None else round(dac_tflops, 3),
             "dAC_frac_of_fp64_mfma_peak": None if dac_tflops is None else round(dac_tflops / FP64_MFMA_PEAK_TFLOPS, 4),
+            "operator_applications_per_site": args.matvecs,       # the galerkin image reuses the eigensolver's first matvec
+            "to_tolerance": to_tol,
             "max_galerkin_last_sweep": None if eps is None else float(max(eps)),
             "qr_calls_timed": {k: be.qr_stats()[k] - qr0[k] for k in qr0},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, D, d)
+            out["cpu_baseline"] = cpu_baseline(L, D, d, args.matvecs)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_shard:
         dist.destroy_process_group()

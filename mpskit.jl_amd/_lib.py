@@ -127,6 +127,44 @@ def load():
     return lib
 
 
+COMM_PATH = os.path.join(_HERE, "libmpsk_comm.so")
+COMM_SIGNATURES = {
+    "mpsk_comm_unique_id": [C.c_void_p],
+    "mpsk_comm_create": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_void_pp],
+    "mpsk_comm_destroy": [C.c_void_p],
+    "mpsk_comm_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "mpsk_comm_allgather": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "mpsk_comm_allreduce_sum": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "mpsk_comm_hac_apply": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int],
+}
+COMM_ID_BYTES = 128
+_comm = None
+
+
+def load_comm():
+    """dlopen libmpsk_comm.so (include/mpsk_comm.h: RCCL all-gather / all-reduce on the ctx stream behind a C ABI)."""
+    global _comm
+    if _comm is not None:
+        return _comm
+    load()
+    if not os.path.exists(COMM_PATH):
+        raise MpskError(f"{COMM_PATH} not found: build it with __graft_entry__.build()")
+    lib = C.CDLL(COMM_PATH)
+    for name, argtypes in COMM_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.mpsk_comm_last_error.restype = C.c_char_p
+    lib.mpsk_comm_last_error.argtypes = []
+    _comm = lib
+    return lib
+
+
+def check_comm(rc, what=""):
+    if rc != 0:
+        raise MpskError(f"{what} failed (code {rc}): {load_comm().mpsk_comm_last_error().decode('utf-8', 'replace')}")
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = load().mpsk_last_error().decode("utf-8", "replace")

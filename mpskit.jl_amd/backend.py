@@ -86,7 +86,8 @@ class Backend:
         return {"cholqr3": a.value, "householder": b.value, "fallback": f.value, "robust": r.value}
 
     def set_svd_mode(self, precondition=True):
-        check(self.lib.mpsk_ctx_set_svd_mode(self.ctx, int(bool(precondition))), "mpsk_ctx_set_svd_mode")
+        """0 / False: Jacobi on theta itself; 1 / True: QR-preconditioned; 2: QR + QR of R^T (mpsk_tsplit only)."""
+        check(self.lib.mpsk_ctx_set_svd_mode(self.ctx, int(precondition)), "mpsk_ctx_set_svd_mode")
 
     def svd_sweeps(self):
         n = C.c_int()

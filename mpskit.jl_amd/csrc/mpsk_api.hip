@@ -60,7 +60,7 @@ struct mpsk_ctx {
   double* h_scal = nullptr;     // pinned host mirror
   int dtype = MPSK_F64;         // scalar type of the slice-less entry points (mpsk_ctx_set_dtype)
   int last_svd_sweeps = 0;
-  int svd_precondition = 1;     // QR-preconditioned Jacobi (mpsk_ctx_set_svd_mode)
+  int svd_precondition = 2;     // mpsk_ctx_set_svd_mode: 0 plain, 1 QR-preconditioned, 2 QR + QR of R^T (mpsk_tsplit; mpsk_tsvd treats it as 1)
   int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
   int* d_flag = nullptr;
   long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0, n_qr_robust = 0;
@@ -1142,7 +1142,8 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   HIPCHK(hipSetDevice(c->device));
   const auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };
   const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);
-  const size_t need = sizeof(double) * (a_d + q_d + 2 * r_d + 8);
+  const size_t t_d = ev((size_t)mm * nn);
+  const size_t need = sizeof(double) * (a_d + q_d + 2 * r_d + t_d + 8);
   if (c->ws3_bytes < need) {
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->stream2));
@@ -1152,9 +1153,10 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
     c->ws3_bytes = need;
   }
   double* At = (double*)c->ws3;            // theta^T when m < n
-  double* Qb = At + a_d;                   // Q of the preconditioning, later theta * Y_k / Y_k^T theta
-  double* Rb = Qb + q_d;                   // R (nn x nn)
-  double* Y = Rb + r_d;                    // sorted, normalised singular vectors of the short side (nn x nn)
+  double* Qb = At + a_d;                   // Q of the preconditioning QR of the tall orientation A' (mm x nn)
+  double* Rb = Qb + q_d;                   // R (nn x nn); R1 of the second pass
+  double* Y = Rb + r_d;                    // sorted, normalised singular vectors from the Jacobi iteration (nn x nn)
+  double* T = Y + r_d;                     // scratch: R^T, then theta V_k / U_k^T theta
   const double* Ap = (const double*)theta;
   int lda = ldt;
   if (transposed) {
@@ -1164,32 +1166,61 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   const size_t qws = sizeof(double) * qr_ws_doubles(mm, nn), sws = tsvd_workspace_bytes(nn, nn);
   if (int rc = ensure_ws(c, (qws > sws ? qws : sws) + 256)) return rc;
   if (int rc = qrpos_dispatch(c, mm, nn, Ap, lda, Qb, mm, Rb, nn, (double*)c->ws)) return rc;
+  // Double preconditioning (svd mode 2, Drmac-Veselic: "QR of R^T"): R^T = Q1 R1, Jacobi on the columns of R1^T.
+  // A' = Qb R = Qb R1^T Q1^T, and R1^T W = G = Y Sigma at convergence, so  A' = (Qb Y) Sigma (Q1 W)^T : the V-free
+  // iteration now yields the LEFT singular vectors Qb Y of the tall orientation (orthonormal to rounding as a product of
+  // orthonormal factors) and costs fewer sweeps (9 -> 6 at n = 512, 10 -> 7 at n = 1024 in the block-Jacobi model with
+  // exact inner solves; measured sweep counts: profiles/r02_svd_modes.log) for one extra n x n QRpos.
+  const bool dbl = c->svd_precondition == 2;
+  if (dbl) {
+    HIPCHK(transpose(Rb, nn, nn, nn, T, nn, c->stream));
+    if (int rc = qrpos_dispatch(c, nn, nn, T, nn, Y, nn, Rb, nn, (double*)c->ws)) return rc;     // Y = Q1 (not needed), Rb = R1
+  }
   std::string err;
   hipError_t e = tsvd(nn, nn, Rb, nn, Y, nn, (double*)S, nullptr, 1, max_keep, trunc_err, kept, disc_norm, c->ws, c->stream,
                       &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, nullptr, /*vfree=*/1);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
   const int k = *kept;
   REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");
-  if (!transposed) {
-    // theta (m x n): Y_k = right singular vectors.  B = theta Y_k = U_k S_k ; AL C = QRpos(B) ; AR = Y_k^T
-    GemmArgs g = mk((const double*)theta, Y, Qb, m, k, n, ldt, nn, m);
+  if (!dbl) {
+    if (!transposed) {
+      // theta (m x n): Y_k = right singular vectors.  B = theta Y_k = U_k S_k ; AL C = QRpos(B) ; AR = Y_k^T
+      GemmArgs g = mk((const double*)theta, Y, T, m, k, n, ldt, nn, m);
+      HIPCHK(gemm_f64(g, c->stream));
+      if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
+      HIPCHK(transpose(Y, nn, n, k, (double*)AR, ldar, c->stream));
+    } else {
+      // theta (m x n), m < n: Y_k = left singular vectors = AL.  M = Y_k^T theta = S_k V_k^T ; C AR = LQpos(M)
+      HIPCHK(hipMemcpy2DAsync(AL, sizeof(double) * ldal, Y, sizeof(double) * nn, sizeof(double) * m, k,
+                              hipMemcpyDeviceToDevice, c->stream));
+      GemmArgs g = mk(Y, (const double*)theta, T, k, n, m, nn, ldt, k, 1, 0);
+      HIPCHK(gemm_f64(g, c->stream));
+      if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
+    }
+  } else if (!transposed) {
+    // A' = theta: AL = Qb Y_k (left singular vectors).  M = AL^T theta = S_k V_k^T ; C AR = LQpos(M)
+    GemmArgs g = mk(Qb, Y, (double*)AL, m, k, n, mm, nn, ldal);
     HIPCHK(gemm_f64(g, c->stream));
-    if (int rc = mpsk_qrpos(c, m, k, Qb, m, AL, ldal, Cm, ldc)) return rc;
-    HIPCHK(transpose(Y, nn, n, k, (double*)AR, ldar, c->stream));
+    GemmArgs g2 = mk((const double*)AL, (const double*)theta, T, k, n, m, ldal, ldt, k, 1, 0);
+    HIPCHK(gemm_f64(g2, c->stream));
+    if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
   } else {
-    // theta (m x n), m < n: Y_k = left singular vectors = AL.  M = Y_k^T theta = S_k V_k^T ; C AR = LQpos(M)
-    HIPCHK(hipMemcpy2DAsync(AL, sizeof(double) * ldal, Y, sizeof(double) * nn, sizeof(double) * m, k,
-                            hipMemcpyDeviceToDevice, c->stream));
-    GemmArgs g = mk(Y, (const double*)theta, Qb, k, n, m, nn, ldt, k, 1, 0);
+    // A' = theta^T (n x m): V_k = Qb Y_k = right singular vectors of theta.  B = theta V_k = U_k S_k ; AL C = QRpos(B) ; AR = V_k^T
+    double* Vk = At;                       // theta^T is no longer needed (n x k <= n x m)
+    GemmArgs g = mk(Qb, Y, Vk, n, k, m, mm, nn, n);
     HIPCHK(gemm_f64(g, c->stream));
-    if (int rc = mpsk_lqpos(c, k, n, Qb, k, Cm, ldc, AR, ldar)) return rc;
+    GemmArgs g2 = mk((const double*)theta, Vk, T, m, k, n, ldt, n, m);
+    HIPCHK(gemm_f64(g2, c->stream));
+    if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
+    HIPCHK(transpose(Vk, n, n, k, (double*)AR, ldar, c->stream));
   }
   return MPSK_OK;
 }
 
 int mpsk_ctx_set_svd_mode(mpsk_ctx* c, int precondition) {
   REQUIRE(c, "ctx is NULL");
-  c->svd_precondition = precondition ? 1 : 0;
+  REQUIRE(precondition >= 0 && precondition <= 2, "svd mode must be 0 (none), 1 (QR), 2 (QR + QR of R^T, mpsk_tsplit)");
+  c->svd_precondition = precondition;
   return MPSK_OK;
 }
 int mpsk_ctx_svd_stats(mpsk_ctx* c, int* last_sweeps) {

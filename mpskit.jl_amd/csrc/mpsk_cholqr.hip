@@ -190,7 +190,14 @@ __global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, do
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) { yj[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0}; yi[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0}; }
     cq_prod(yj, sM, sJ, 1.0, wr, wc, fr, fq);
-    cq_prod(yi, sM, sI, 1.0, wr, wc, fr, fq);
+    if (i == j) {                            // diagonal tile: the two solved panels coincide (uniform branch)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) yi[ti][tj] = yj[ti][tj];
+    } else {
+      cq_prod(yi, sM, sI, 1.0, wr, wc, fr, fq);
+    }
     __syncthreads();                                        // everyone is done reading the unsolved panels
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(256) void cq_check_identity_kernel(const double* __
   int bad = 0;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     int r = (int)(e % n), c = (int)(e / n);
+    if (r > c) continue;                      // the Gram GEMM fills the upper block triangle only
     double v = G[r + (int64_t)c * npad] - (r == c ? 1.0 : 0.0);
     if (!(fabs(v) <= thresh)) bad = 1;
   }
@@ -339,7 +347,8 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
                           double* Rinv, double* T, bool shifted, bool check_identity, int* flag, hipStream_t s) {
   hipError_t e;
   double* Gw = T;                                                            // Gram matrix, consumed by the factorization
-  GemmArgs g = cq_mk(X, X, Gw, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X
+  GemmArgs g = cq_mk(X, X, Gw, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X: only the upper block triangle
+  g.upper_only = 1;                                                          // is read by the factorization below
   if ((e = gemm_f64(g, s)) != hipSuccess) return e;
   if (npad > n) hipLaunchKernelGGL(cq_pad_identity_kernel, dim3(512), dim3(256), 0, s, Gw, npad, n);
   if (check_identity) hipLaunchKernelGGL(cq_check_identity_kernel, dim3(256), dim3(256), 0, s, Gw, npad, n, 0.5, flag);
@@ -358,6 +367,9 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
   }
   hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
   // R^{-1} by recursive doubling: inv([R11 R12; 0 R22]) = [i11, -i11 R12 i22; 0, i22]
+  // (computing the block columns of R^-1 as extra tiles of the step launches -- X_ic = -(sum_l X_il R_lc) X_cc -- was
+  //  measured and rejected: the serial l-loop of a tile, ~2 us per term, is longer than a step from column 12 on and puts
+  //  the inverse ON the critical path: 1.95 instead of 1.80 ms at 2048 x 1024, 59 instead of 29 ms at 4096^2)
   for (int b = CB; b < npad; b <<= 1) {
     const int pairs = npad / (2 * b);
     const int64_t bs = (int64_t)2 * b * (npad + 1);
@@ -372,8 +384,9 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
     g.batch = pairs; g.bsA = bs; g.bsB = bs; g.bsC = bs;
     if ((e = gemm_f64(g, s)) != hipSuccess) return e;
   }
-  // Q = X R^{-1}
+  // Q = X R^{-1}   (R^-1 upper triangular: column tile n0 only needs k < n0 + 64)
   g = cq_mk(X, Rinv, Q, m, n, n, ldx, npad, ldq, 0, 1.0, 0.0);
+  g.b_upper = 1;
   return gemm_f64(g, s);
 }
 
@@ -398,10 +411,10 @@ __global__ __launch_bounds__(256) void cq_firstorder_kernel(const double* __rest
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     int r = (int)(e % npad), c = (int)(e / npad);
     double u = 0.0, id = (r == c) ? 1.0 : 0.0;
-    if (r < n && c < n) {
+    if (r < n && c < n && r <= c) {           // the Gram GEMM fills the upper block triangle only
       const double ev = G[e] - id;
       if (!(fabs(ev) <= 1.0e-7)) big = 1;
-      u = (r < c) ? ev : (r == c ? 0.5 * ev : 0.0);
+      u = (r < c) ? ev : 0.5 * ev;
     }
     R3[e] = id + u;
     Minv[e] = id - u;
@@ -412,10 +425,12 @@ __global__ __launch_bounds__(256) void cq_firstorder_kernel(const double* __rest
 static hipError_t cq_pass_firstorder(int m, int n, int npad, const double* X, int ldx, double* Q, int ldq, double* Rp,
                                      double* Rinv, double* T, int* flag, hipStream_t s) {
   hipError_t e;
-  GemmArgs g = cq_mk(X, X, T, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X  (into T)
+  GemmArgs g = cq_mk(X, X, T, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X  (into T), upper block triangle
+  g.upper_only = 1;
   if ((e = gemm_f64(g, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(cq_firstorder_kernel, dim3(1024), dim3(256), 0, s, T, npad, n, Rp, Rinv, flag);
   g = cq_mk(X, Rinv, Q, m, n, n, ldx, npad, ldq, 0, 1.0, 0.0);
+  g.b_upper = 1;                                                           // Minv = I - U is upper triangular
   return gemm_f64(g, s);
 }
 
@@ -436,9 +451,12 @@ static CqBufs cq_bufs(int m, int n, double* ws) {
 }
 static hipError_t cq_finish(const CqBufs& b, int n, double* R, int ldr, int* d_flag, int* flag_out, hipStream_t s) {
   hipError_t e;
+  // products of upper triangular factors: only the upper tiles, only the k-tiles between the two diagonals
   GemmArgs g = cq_mk(b.R2, b.R1, b.T, b.npad, b.npad, b.npad, b.npad, b.npad, b.npad, 0, 1.0, 0.0);
+  g.a_upper = g.b_upper = g.upper_only = 1;
   if ((e = gemm_f64(g, s)) != hipSuccess) return e;
   g = cq_mk(b.R3, b.T, b.Rinv, b.npad, b.npad, b.npad, b.npad, b.npad, b.npad, 0, 1.0, 0.0);
+  g.a_upper = g.b_upper = g.upper_only = 1;
   if ((e = gemm_f64(g, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(cq_copy_upper_kernel, dim3(1024), dim3(256), 0, s, b.Rinv, b.npad, n, R, ldr);
   return hipMemcpyAsync(flag_out, d_flag, sizeof(int), hipMemcpyDeviceToHost, s);
@@ -522,6 +540,7 @@ hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int 
   double *X = b.Qa, *Y = b.Qb;
   auto accumulate = [&]() -> hipError_t {    // acc <- cur * acc
     GemmArgs g = cq_mk(cur, acc, tmp, npad, npad, npad, npad, npad, npad, 0, 1.0, 0.0);
+    g.a_upper = g.b_upper = g.upper_only = 1;
     hipError_t ee = gemm_f64(g, s);
     double* t = acc; acc = tmp; tmp = t;
     return ee;

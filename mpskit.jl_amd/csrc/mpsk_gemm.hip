@@ -323,6 +323,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   }
   int bm, bn;
   tile_coords(g, bid, tilesM, tilesN, &bm, &bn);
+  if (g.upper_only && bm > bn) return;      // symmetric result, lower tiles never read (uniform per workgroup)
   const int z = blockIdx.y;
   const int m0 = bm * BM, n0 = bn * BN;
   const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
@@ -334,7 +335,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 #pragma unroll
     for (int j = 0; j < BN / 32; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
   const int nt = ((g.K + BK - 1) / BK) * g.nseg;
-  gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS, CJ>(g, Ab, Bb, z, m0, n0, 0, nt, acc, smem);
+  int ktlo = 0, kthi = nt;
+  if (g.b_upper) { const int lim = (n0 + BN + BK - 1) / BK; if (lim < kthi) kthi = lim; }
+  if (g.a_upper) ktlo = m0 / BK;
+  if (ktlo < kthi) gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS, CJ>(g, Ab, Bb, z, m0, n0, ktlo, kthi, acc, smem);
   gemm_store_c<BM, BN, ALIGNED, CJ>(g, Cb, z, m0, n0, acc);
 }
 
@@ -370,6 +374,7 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
     const int z = tz / ntiles, tile = tz - z * ntiles;
     int bm, bn;
     tile_coords(g, tile, tilesM, tilesN, &bm, &bn);
+    if (g.upper_only && bm > bn) { u += kt1 - kt0; continue; }     // uniform: the whole workgroup skips the share
     const int m0 = bm * BM, n0 = bn * BN;
     const double* Ab = g.A + (g.tabA ? g.tabA[z] : (int64_t)z * g.bsA);
     const double* Bb = g.B + (g.tabB ? g.tabB[z] : (int64_t)z * g.bsB);
@@ -378,7 +383,12 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-    gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS>(g, Ab, Bb, z, m0, n0, kt0, kt1, acc, smem);
+    {
+      int ka = kt0, kb = kt1;                 // triangular operands: clamp the share to the structurally non-zero k-tiles
+      if (g.b_upper) { const int lim = (n0 + BN + BK - 1) / BK; if (lim < kb) kb = lim; }
+      if (g.a_upper) { const int lo = m0 / BK; if (lo > ka) ka = lo; }
+      if (ka < kb) gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS>(g, Ab, Bb, z, m0, n0, ka, kb, acc, smem);
+    }
     // one epilogue for both destinations (uniform parameters): C tile (kt0 == 0) or workspace slot
     const bool toC = (kt0 == 0);
     double* base = toC ? g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC) + m0 + (int64_t)n0 * g.ldc
@@ -437,17 +447,37 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs g) {
   if (i * g.sk_units >= u1) return;            // tile not split
   int bm, bn;
   tile_coords(g, tile, tilesM, tilesN, &bm, &bn);
+  if (g.upper_only && bm > bn) return;
   const int m0 = bm * BM, n0 = bn * BN;
   double* Cb = g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC);
-  for (int e = threadIdx.x; e < BM * BN; e += 256) {
-    const int m = e % BM, n = e / BM;
-    if (m0 + m >= g.M || n0 + n >= g.N) continue;
-    double s = 0.0;
-    for (int w = i; w * g.sk_units < u1; ++w) s += g.sk_ws[(int64_t)w * BM * BN + e];
-    const int gn = n0 + n;
-    double* p = (g.tabC2 != nullptr && gn >= g.splitN) ? g.C + g.tabC2[z] + (m0 + m) + (int64_t)(gn - g.splitN) * g.ldc
-                                                       : Cb + (m0 + m) + (int64_t)gn * g.ldc;
-    *p += s;
+  // 8 elements per thread and pass, every load of a pass issued before the first use: the earlier one-element loop
+  // waited out a full memory round trip per element (23 us per launch for a few MB of traffic)
+  constexpr int UNR = 8;
+  for (int e0 = threadIdx.x; e0 < BM * BN; e0 += 256 * UNR) {
+    double sacc[UNR], cv[UNR];
+    double* pp[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      const int e = e0 + 256 * q;
+      const int m = e % BM, n = e / BM;
+      const bool ok = (e < BM * BN) && (m0 + m < g.M) && (n0 + n < g.N);
+      const int gn = n0 + n;
+      pp[q] = !ok ? nullptr
+                  : ((g.tabC2 != nullptr && gn >= g.splitN) ? g.C + g.tabC2[z] + (m0 + m) + (int64_t)(gn - g.splitN) * g.ldc
+                                                            : Cb + (m0 + m) + (int64_t)gn * g.ldc);
+      cv[q] = ok ? *pp[q] : 0.0;
+      sacc[q] = 0.0;
+    }
+    for (int w = i; w * g.sk_units < u1; ++w) {
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        const int e = e0 + 256 * q;
+        if (e < BM * BN) sacc[q] += g.sk_ws[(int64_t)w * BM * BN + e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < UNR; ++q)
+      if (pp[q]) *pp[q] = cv[q] + sacc[q];
   }
 }
 
@@ -665,6 +695,8 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   g.sk_units = 0;
   g.sk_ws = nullptr;
   if (g.cplx && g.c_rs == 0) g.c_rs = 1;
+  if (g.upper_only && g.M != g.N) g.upper_only = 0;
+  if (g.nseg != 1 || g.transA || g.transB) g.a_upper = g.b_upper = 0;
   if (g_force_bm.load()) { bm = g_force_bm.load(); bn = g_force_bn.load(); }
   else if (g.cplx) { /* no split-K / stream-K: the complex epilogue lives in gemm_store_c only */ }
   else {
@@ -717,6 +749,7 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   if (!g.zsegA) for (int i = 0; i < g.nseg && i < MAXSEG; ++i) aligned = aligned && (g.segA[i] % 2 == 0);
   if (!g.zsegB) for (int i = 0; i < g.nseg && i < MAXSEG; ++i) aligned = aligned && (g.segB[i] % 2 == 0);
   if ((!g.zsegA || !g.zsegB) && g.nseg > MAXSEG) return hipErrorInvalidValue;
+  if (g.upper_only && bm != bn) g.upper_only = 0;     // the tile test bm > bn needs square tiles
 #define MPSK_DISPATCH(TA_, TB_)                                                        \
   return aligned ? launch_tile<TA_, TB_, true>(g, bm, bn, s) : launch_tile<TA_, TB_, false>(g, bm, bn, s)
   if (!g.transA && !g.transB) { MPSK_DISPATCH(false, false); }

@@ -61,6 +61,10 @@ struct GemmArgs {
   // loader (the real kernels do not carry the test).  c_rs: row stride of C (1, or 2 to write one plane of an interleaved
   // complex result: transfer_left's Ab^H T2).
   signed char segJ[MAXSEG];
+  int b_upper, a_upper;      // operand is upper triangular (single K segment, K index aligned with N resp. M): k-tiles that
+                             // only meet structural zeros are skipped -- B upper: k < n0 + BN ; A upper: k >= m0
+  int upper_only;            // C is symmetric (Gram matrix) and only its upper triangle is consumed: tiles strictly below the
+                             // block diagonal are skipped (M == N, square tiles)
   int cplx;
   int c_rs;
   int tag;                   // 1: matvec-stage launch (own kernel symbol + event profile)

@@ -124,6 +124,62 @@ class Comm:
         return float(t.item())
 
 
+class LibComm(Comm):
+    """The same two collectives through libmpsk_comm (include/mpsk_comm.h): RCCL called from the C ABI on the ctx
+    stream -- what a host without torch.distributed (the Julia shim) binds.  `uid`: the MPSK_COMM_ID_BYTES of rank 0's
+    mpsk_comm_unique_id, shipped to every rank by the host (here: any transport, e.g. a torch.distributed broadcast)."""
+
+    def __init__(self, be, world=1, rank=0, uid=None):
+        import ctypes as C
+        from . import _lib
+        super().__init__(world, rank)
+        self.be, self.lib = be, _lib.load_comm()
+        if uid is None:
+            if world != 1:
+                raise ValueError("ranks > 0 need rank 0's unique id")
+            uid = self.unique_id()
+        self._uid = C.create_string_buffer(bytes(uid), _lib.COMM_ID_BYTES)
+        h = C.c_void_p()
+        _lib.check_comm(self.lib.mpsk_comm_create(be.ctx, world, rank, self._uid, C.byref(h)), "mpsk_comm_create")
+        self.handle = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check_comm(_lib.load_comm().mpsk_comm_unique_id(buf), "mpsk_comm_unique_id")
+        return buf.raw
+
+    def all_gather_into(self, out, inp):
+        from . import _lib
+        self.n_allgather += 1
+        self.bytes_allgather += out.numel() * 8
+        _lib.check_comm(self.lib.mpsk_comm_allgather(self.handle, inp.data_ptr(), out.data_ptr(), inp.numel()),
+                        "mpsk_comm_allgather")
+        return out
+
+    def all_reduce_sum(self, buf):
+        from . import _lib
+        self.n_allreduce += 1
+        self.bytes_allreduce += buf.numel() * 8
+        _lib.check_comm(self.lib.mpsk_comm_allreduce_sum(self.handle, buf.data_ptr(), buf.numel()), "mpsk_comm_allreduce_sum")
+        return buf
+
+    def hac_apply(self, hac, xb, out):
+        """mpsk_comm_hac_apply: local rows into this rank's block of `out` + the in-place all-gather, one C call."""
+        from . import _lib
+        Dl, d, Dr = xb.shape
+        self.n_allgather += 1
+        _lib.check_comm(self.lib.mpsk_comm_hac_apply(self.handle, hac.handle, xb.ptr, out.ptr, Dl, d, Dr), "mpsk_comm_hac_apply")
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mpsk_comm_destroy(self.handle)
+            self.handle = None
+
+
 # ---- layout helpers (device copies through mpsk_copy2d; once per site visit, never per matvec) --------------------
 
 def _sub(t: DTensor, offset, shape):

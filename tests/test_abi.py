@@ -39,6 +39,20 @@ def test_ctypes_binding_covers_the_header():
     assert lib.mpsk_version() >= 100
 
 
+def test_comm_library_exports_its_header():
+    """include/mpsk_comm.h (RCCL collectives behind the C ABI): every declared symbol is exported and bound."""
+    from mpskit_jl_amd import _lib
+    src = open(os.path.join(ROOT, "include", "mpsk_comm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mpsk_comm_[A-Za-z0-9_]+)\s*\(", src)))
+    assert "mpsk_comm_allgather" in syms and "mpsk_comm_allreduce_sum" in syms and "mpsk_comm_hac_apply" in syms
+    assert os.path.exists(_lib.COMM_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load_comm()
+    missing = [s_ for s_ in syms if not hasattr(lib, s_)]
+    assert not missing, missing
+    assert set(syms) <= set(_lib.COMM_SIGNATURES) | {"mpsk_comm_last_error"}
+
+
 def test_no_cpu_fallback():
     import torch
     import mpskit_jl_amd as mk

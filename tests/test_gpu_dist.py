@@ -20,3 +20,43 @@ def test_two_ranks_on_one_gpu_host_staged():
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-2000:]}"
         assert "OK" in o
+
+
+def test_libmpsk_comm_world1(be):
+    """include/mpsk_comm.h on the GPU at world size 1 (the only size a one-GPU box allows: RCCL refuses duplicate
+    devices): RCCL communicator from the C ABI, in-place all-gather / all-reduce on the ctx stream, and one sharded
+    application of a prepared operator (mpsk_comm_hac_apply) == mpsk_dAC.  The sharded sweep through this communicator
+    equals the unsharded sweep."""
+    import numpy as np
+    import torch
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import dist as md, algorithms as alg, krylov
+    comm = md.LibComm(be, 1, 0)
+    try:
+        t = torch.arange(1000, dtype=torch.float64, device=be.device)
+        ref = t.clone()
+        comm.all_gather_into(t, t)                  # in place
+        comm.all_reduce_sum(t)
+        be.synchronize()
+        assert torch.equal(t, ref)
+        rng = np.random.default_rng(4)
+        D, d, W = 128, 2, 5
+        H = mk.heisenberg_XXX(0.5, be=be)
+        GL = be.upload_env([rng.standard_normal((D, 1, D)) for _ in range(W)])
+        GR = be.upload_env([rng.standard_normal((D, 1, D)) for _ in range(W)])
+        x = be.upload(rng.standard_normal((D, d, D)))
+        hac = be.hac_create(H[1], GL, GR)
+        y = comm.hac_apply(hac, md.to_blocked(be, x, 1), be.empty(D, d, D))
+        yref = be.dAC(H[1], GL, GR, x)
+        assert np.abs(be.download(y) - be.download(yref)).max() <= 1e-13 * np.abs(be.download(yref)).max()
+        psi = mk.FiniteMPS.random(12, 2, 64, np.random.default_rng(1), be=be)
+        ps = psi.copy()
+        eig = mk.Arnoldi(fixed_matvecs=4, krylovdim=4)
+        eu, es = mk.FinEnv(psi, H), md.ShardedFinEnv(ps, H, comm, min_block=32, force=True)
+        alg.dmrg_sweep(psi, H, eu, eig, krylov.KrylovWorkspace(be))
+        alg.dmrg_sweep(ps, H, es, eig, krylov.KrylovWorkspace(be))
+        e1 = float(np.sum(mk.expectation_value(psi, H, eu)))
+        e2 = float(np.sum(mk.expectation_value(ps, H, es)))
+        assert abs(e1 - e2) <= 1e-10 * abs(e1) and comm.n_allgather > 10
+    finally:
+        comm.close()

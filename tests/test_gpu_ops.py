@@ -476,8 +476,9 @@ def test_qrlq_pair(be, m, n):
     assert relerr(Q1, Qs) < 1e-12 and relerr(L2, Ls) < 1e-11 and relerr(Q2, Qls) < 1e-10
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("m,n,k", [(512, 384, 100), (384, 512, 100), (1024, 1024, 256), (200, 130, 0)])
-def test_tsplit(be, m, n, k):
+def test_tsplit(be, m, n, k, mode):
     """mpsk_tsplit (V-free Jacobi + rebuilt factor): al, ar isometries, al c ar = the optimal rank-k truncation of theta
     (same singular values / discarded norm as numpy), c triangular, for both orientations and a graded spectrum."""
     rng = np.random.default_rng(m + 3 * n + k)
@@ -486,7 +487,11 @@ def test_tsplit(be, m, n, k):
     Vo, _ = np.linalg.qr(rng.standard_normal((n, r)))
     s = np.logspace(0, -9, r)
     A = (Uo * s) @ Vo.T
-    al, c, ar, S, disc = be.tsplit(be.upload(A), max_keep=k)
+    be.set_svd_mode(mode)          # 1: QR-preconditioned, 2: QR + QR of R^T (left singular vectors come out of the iteration)
+    try:
+        al, c, ar, S, disc = be.tsplit(be.upload(A), max_keep=k)
+    finally:
+        be.set_svd_mode(1)
     kk = k if k > 0 else r
     al, c, ar = be.download(al), be.download(c), be.download(ar)
     assert al.shape == (m, kk) and c.shape == (kk, kk) and ar.shape == (kk, n)
