@@ -60,7 +60,7 @@ def c4(be):
     print(f"c4 dAC2 D=1024 d=4 W=6: {dt * 1e3:.2f} ms = {fl / dt / 1e12:.1f} TFLOP/s (algorithmic {fl / 1e9:.0f} GF)", flush=True)
 
 
-def c4sweep(be, L=16, D=256):
+def c4sweep(be, L=16, D=256, nsweeps=2):
     """Two-site DMRG sweeps (Hubbard U/t = 4, d = 4) with tsvd! truncation to D: time split eigsolve / tsvd and the
     Jacobi sweep counts on the theta tensors a real run produces (graded Schmidt spectra)."""
     H = mk.hubbard(1.0, 4.0, be=be)
@@ -83,7 +83,7 @@ def c4sweep(be, L=16, D=256):
 
     be.tsplit, alg.fixedpoint = tsvd_timed, fp_timed
     try:
-        for it in range(2):
+        for it in range(nsweeps):
             for k in stat:
                 stat[k] = [] if k == "sweeps" else 0
             q0 = be.qr_stats()

@@ -1,7 +1,7 @@
 """Parse rocprofv3 --pmc counter CSVs (FETCH_SIZE / WRITE_SIZE passes) into per-launch HBM bytes per
 kernel, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): counters are in KiB,
 FETCH_SIZE reports exactly 1/2 of the bytes of wide (16 B/lane) coalesced reads -> doubled.
-usage: pmc_traffic.py <dir with *counter_collection.csv> [<dir> ...] > profiles/r01_pmc_traffic.json"""
+usage: pmc_traffic.py <dir with *counter_collection.csv> [<dir> ...] > profiles/r02_pmc_traffic.json"""
 import csv, glob, json, os, sys
 acc = {}
 for d in sys.argv[1:]:
@@ -20,4 +20,7 @@ for k, v in acc.items():
     out[k] = rd + wr                                        # what bench.py puts into roofline.traffic
     out[k + "/detail"] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                           "launches_sampled": max(fetch[1], write[1])}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["kernel_source_sha256_16"] = bench.kernel_source_hash()      # bench.py attaches the figures only to these sources
 print(json.dumps(out, indent=1, sort_keys=True))
