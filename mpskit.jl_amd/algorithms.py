@@ -314,11 +314,12 @@ def _dmrg2(psi, H, alg: DMRG2, envs=None):  # dmrg.jl:80-137
 
 # ---- VUMPS ----------------------------------------------------------------------------------------
 
-def regauge(be, AC: DTensor, C: DTensor):
+def regauge(be, AC: DTensor, C: DTensor, cplx=False):
     """regauge!(AC, C; alg = QRpos()) -> AL = Q_AC Q_C^dag   (ortho.jl:127-131)."""
+    from .states import _qr
     Dl, d, Dr = AC.shape
-    Qac, _ = be.qrpos(AC.reshape(Dl * d, Dr))
-    Qc, _ = be.qrpos(C)
+    Qac, _ = _qr(be, AC.reshape(Dl * d, Dr), cplx)
+    Qc, _ = _qr(be, C, cplx)
     return be.gemm(Qac, Qc, transB=True).reshape(Dl, d, Dr)
 
 
@@ -341,9 +342,9 @@ def _vumps(psi, H, alg: VUMPS, envs=None):  # vumps.jl:29-92
         for loc in range(n):
             _, AC = fixedpoint(be, ddAC(loc, psi, H, envs), psi.AC[loc], eig, ws)
             _, C = fixedpoint(be, ddC(loc, psi, H, envs), psi.CR[loc], eig, ws)
-            newAL.append(regauge(be, AC, C))
+            newAL.append(regauge(be, AC, C, getattr(psi, "cplx", False)))
         gtol = updatetol(alg.gauge_tol_min, alg.gauge_tol_max, alg.gauge_tol_factor, it, eps)
-        psi = InfiniteMPS.from_AL(newAL, psi.CR[n - 1], tol=gtol, be=be)
+        psi = InfiniteMPS.from_AL(newAL, psi.CR[n - 1], tol=gtol, be=be, cplx=getattr(psi, "cplx", False))
         etol = updatetol(alg.env_tol_min, alg.env_tol_max, alg.env_tol_factor, it, eps)
         envs.recalculate(psi, etol)
         if alg.finalize is not None:
@@ -478,8 +479,9 @@ def _timestep_inf(psi, H, t, dt, alg: TDVP, envs):  # tdvp.jl:21-59 (leftorthfla
     for loc in range(n):
         ac = integrate(be, ddAC(loc, psi, H, envs), psi.AC[loc], t, dt, alg, ws)
         c = integrate(be, ddC(loc, psi, H, envs), psi.CR[loc], t, dt, alg, ws)
-        newAL.append(regauge(be, ac, c))
-    psi2 = InfiniteMPS.from_AL(newAL, psi.CR[n - 1], tol=alg.tolgauge, maxiter=alg.gaugemaxiter, be=be)
+        newAL.append(regauge(be, ac, c, getattr(psi, "cplx", False)))
+    psi2 = InfiniteMPS.from_AL(newAL, psi.CR[n - 1], tol=alg.tolgauge, maxiter=alg.gaugemaxiter, be=be,
+                               cplx=getattr(psi, "cplx", False))
     envs.recalculate(psi2)
     return psi2, envs
 

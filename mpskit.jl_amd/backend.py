@@ -348,6 +348,21 @@ class Backend:
         check(self.lib.mpsk_gemm(self.ctx, int(transA), int(transB), M, N, K, float(alpha), a_ptr, lda, b_ptr,
                                  ldb, float(beta), c_ptr, ldc), "mpsk_gemm")
 
+    def triu_(self, M: DTensor):
+        """zero the strictly lower triangle of a column-major matrix in place (torch view of the buffer: a fill, no arithmetic)."""
+        torch = _torch()
+        r, c = M.shape
+        v = torch.as_strided(M.buf, (r, c), (1, r))
+        v.copy_(torch.triu(v))
+        return M
+
+    def tril_(self, M: DTensor):
+        torch = _torch()
+        r, c = M.shape
+        v = torch.as_strided(M.buf, (r, c), (1, r))
+        v.copy_(torch.tril(v))
+        return M
+
     def copy2d(self, rows, cols, src_ptr, lds, dst_ptr, ldd):
         check(self.lib.mpsk_copy2d(self.ctx, rows, cols, src_ptr, lds, dst_ptr, ldd), "mpsk_copy2d")
 

@@ -16,21 +16,58 @@ from . import krylov
 
 # ---- gauge primitives on device tensors -------------------------------------------------------
 
-def leftorth(be: Backend, A: DTensor):
+def _structured(be, cplx):
+    """embedded complex tensors on a device backend: the gauge steps must return embeddings (cplx.qrpos_structured)."""
+    return cplx and hasattr(be, "times_i") and hasattr(be, "triu_")
+
+
+def _qr(be, M, cplx=False):
+    if _structured(be, cplx):
+        from .cplx import qrpos_structured
+        return qrpos_structured(be, M)
+    return be.qrpos(M)
+
+
+def _lq(be, M, cplx=False):
+    if _structured(be, cplx):
+        from .cplx import lqpos_structured
+        return lqpos_structured(be, M)
+    return be.lqpos(M)
+
+
+def leftorth(be: Backend, A: DTensor, cplx=False):
     """A[a,s,b] -> AL[a,s,k], C[k,b], diag(C) > 0   (leftorth(A; alg = QRpos()), orthoview.jl:56)."""
     Dl, d, Dr = A.shape
     if Dl * d < Dr:
         raise ValueError(f"leftorth: tensor {A.shape} is not full column rank shaped (Dl*d < Dr)")
-    Q, R = be.qrpos(A.reshape(Dl * d, Dr))
+    if _structured(be, cplx):
+        from .cplx import qrpos_structured
+        Q, R = qrpos_structured(be, A.reshape(Dl * d, Dr))
+    else:
+        Q, R = be.qrpos(A.reshape(Dl * d, Dr))
     return Q.reshape(Dl, d, Dr), R
 
 
-def rightorth(be: Backend, A: DTensor):
+def rightorth(be: Backend, A: DTensor, cplx=False):
     """A[a,s,b] -> C[a,k], AR[k,s,b], diag(C) > 0   (rightorth(_transpose_tail(A); alg = LQpos()),
     orthoview.jl:52-54)."""
     Dl, d, Dr = A.shape
     if Dl > d * Dr:
         raise ValueError(f"rightorth: tensor {A.shape} is not full row rank shaped (Dl > d*Dr)")
+    if _structured(be, cplx):
+        # the (b, s) tail of A[a, (s, b)] carries the embedding on b (slowest): as a matrix Dl x (d Dr) the 2x2 blocks
+        # sit on (row pair, column pair) with columns (s, 2b + beta) -> beta is NOT the fastest column index; go through
+        # the [a; (b, s)]-ordered copy, whose column pairs are adjacent
+        from .cplx import lqpos_structured
+        At = be.empty(Dl, Dr, d)                              # At[a, b, s] = A[a, s, b]
+        for s_ in range(d):
+            be.copy2d(Dl, Dr, A.ptr + 8 * s_ * Dl, Dl * d, At.ptr + 8 * s_ * Dl * Dr, Dl)
+        # columns of At as a matrix: (b, s) with b fastest -> pairs (2b, 2b + 1) adjacent
+        L, Qt = lqpos_structured(be, At.reshape(Dl, Dr * d))
+        Q = be.empty(Dl, d, Dr)
+        for s_ in range(d):
+            be.copy2d(Dl, Dr, Qt.ptr + 8 * s_ * Dl * Dr, Dl, Q.ptr + 8 * s_ * Dl, Dl * d)
+        return L, Q
     L, Q = be.lqpos(A.reshape(Dl, d * Dr))
     return L, Q.reshape(Dl, d, Dr)
 
@@ -68,7 +105,7 @@ class FiniteMPS:
         for i in range(N):
             if C is not None:
                 As[i] = mul_CA(be, C, As[i])
-            As[i], C = leftorth(be, As[i])
+            As[i], C = leftorth(be, As[i], self.cplx)
             if normalize:
                 be.scal(nrm_target / be.norm(C), C)
         self.N = N
@@ -116,10 +153,10 @@ class FiniteMPS:
     def CR(self, i):  # :49-60
         if self.CLs[i + 1] is None:
             if i == -1 or self.ALs[i] is not None:
-                C, ar = rightorth(self.be, self.AC(i + 1))
+                C, ar = rightorth(self.be, self.AC(i + 1), self.cplx)
                 self.CLs[i + 1], self.ARs[i + 1] = C, ar
             else:
-                al, C = leftorth(self.be, self.AC(i))
+                al, C = leftorth(self.be, self.AC(i), self.cplx)
                 self.ALs[i], self.CLs[i + 1] = al, C
         return self.CLs[i + 1]
 
@@ -154,10 +191,10 @@ class FiniteMPS:
     def set_CR(self, i, vec):  # CRView.setindex!  orthoview.jl:62-78
         if self.CLs[i + 1] is None:
             if self.ALs[i] is not None:
-                C, ar = rightorth(self.be, self.AC(i + 1))
+                C, ar = rightorth(self.be, self.AC(i + 1), self.cplx)
                 self.CLs[i + 1], self.ARs[i + 1] = C, ar
             else:
-                al, C = leftorth(self.be, self.AC(i))
+                al, C = leftorth(self.be, self.AC(i), self.cplx)
                 self.ALs[i], self.CLs[i + 1] = al, C
         self.ACs = [None] * self.N
         self.CLs = [None] * (self.N + 1)
@@ -174,7 +211,7 @@ class FiniteMPS:
         factorizations are issued TOGETHER (mpsk_qrpos2) and the state is left exactly as the lazy views
         would leave it.  Returns the OLD AL[i] (the galerkin projector)."""
         be = self.be
-        if self.ALs[i] is not None or self.ACs[i] is None or not hasattr(be, "qrpos2"):
+        if self.ALs[i] is not None or self.ACs[i] is None or not hasattr(be, "qrpos2") or _structured(be, self.cplx):
             al_old = self.AL(i)
             self.set_AC(i, vec)
             return al_old
@@ -228,7 +265,7 @@ def _transfer_right_bond(be, v, A, Ab, out=None):
     return r.reshape(r.shape[1], r.shape[2])
 
 
-def uniform_leftorth(be, A, C0, tol=1e-14, maxiter=100, eig_miniter=10):
+def uniform_leftorth(be, A, C0, tol=1e-14, maxiter=100, eig_miniter=10, cplx=False):
     """ortho.jl uniform_leftorth!: iterate {optional Arnoldi on flip(TransferMatrix(A, AL));
     per site C.A -> QRpos} until ||C0 - C1|| < tol.  Returns (AL list, CR list)."""
     n = len(A)
@@ -249,10 +286,10 @@ def uniform_leftorth(be, A, C0, tol=1e-14, maxiter=100, eig_miniter=10):
                 be.axpby(1.0, cur, 0.0, out)
                 return out
             _, vec = krylov.eigsolve_lm_real(be, tm, CR[n - 1], tol=etol)
-            _, CR[n - 1] = be.qrpos(vec)
+            _, CR[n - 1] = _qr(be, vec, cplx)
         C0_ = CR[n - 1]
         for i in range(n):
-            AL[i], CR[i] = leftorth(be, mul_CA(be, CR[(i - 1) % n], A[i]))
+            AL[i], CR[i] = leftorth(be, mul_CA(be, CR[(i - 1) % n], A[i]), cplx)
         be.scal(1.0 / be.norm(CR[n - 1]), CR[n - 1])
         diff = be.copy(C0_)
         be.axpby(-1.0, CR[n - 1], 1.0, diff)
@@ -262,7 +299,7 @@ def uniform_leftorth(be, A, C0, tol=1e-14, maxiter=100, eig_miniter=10):
             return AL, CR
 
 
-def uniform_rightorth(be, A, C0, tol=1e-14, maxiter=100, eig_miniter=10):
+def uniform_rightorth(be, A, C0, tol=1e-14, maxiter=100, eig_miniter=10, cplx=False):
     n = len(A)
     CR = [None] * n
     c = be.copy(C0)
@@ -281,10 +318,10 @@ def uniform_rightorth(be, A, C0, tol=1e-14, maxiter=100, eig_miniter=10):
                 be.axpby(1.0, cur, 0.0, out)
                 return out
             _, vec = krylov.eigsolve_lm_real(be, tm, CR[n - 1], tol=etol)
-            CR[n - 1], _ = be.lqpos(vec)
+            CR[n - 1], _ = _lq(be, vec, cplx)
         C0_ = CR[n - 1]
         for i in range(n - 1, -1, -1):
-            CR[(i - 1) % n], AR[i] = rightorth(be, mul_AC(be, A[i], CR[i]))
+            CR[(i - 1) % n], AR[i] = rightorth(be, mul_AC(be, A[i], CR[i]), cplx)
         be.scal(1.0 / be.norm(CR[n - 1]), CR[n - 1])
         diff = be.copy(C0_)
         be.axpby(-1.0, CR[n - 1], 1.0, diff)
@@ -313,20 +350,22 @@ class InfiniteMPS:
             A = [embed(np.asarray(a)) for a in A]
         A = [a if isinstance(a, DTensor) else be.upload(np.asarray(a)) for a in A]
         D = A[0].shape[0]
-        AL, CR = uniform_leftorth(be, A, be.upload(np.eye(D)), tol, maxiter)
-        AR, CR = uniform_rightorth(be, AL, CR[-1], tol, maxiter)
+        AL, CR = uniform_leftorth(be, A, be.upload(np.eye(D)), tol, maxiter, cplx=cx)
+        AR, CR = uniform_rightorth(be, AL, CR[-1], tol, maxiter, cplx=cx)
         AC = [mul_AC(be, AL[i], CR[i]) for i in range(len(A))]
         out = cls(AL, AR, CR, AC, be)
         out.cplx = cx
         return out
 
     @classmethod
-    def from_AL(cls, AL, C0, tol=1e-14, maxiter=100, be=None):
+    def from_AL(cls, AL, C0, tol=1e-14, maxiter=100, be=None, cplx=False):
         """infinitemps.jl:172-186 (gaugefix! order = :R)."""
         be = default_backend() if be is None else be
-        AR, CR = uniform_rightorth(be, AL, C0, tol, maxiter)
+        AR, CR = uniform_rightorth(be, AL, C0, tol, maxiter, cplx=cplx)
         AC = [mul_AC(be, AL[i], CR[i]) for i in range(len(AL))]
-        return cls(list(AL), AR, CR, AC, be)
+        out = cls(list(AL), AR, CR, AC, be)
+        out.cplx = cplx
+        return out
 
     @classmethod
     def random(cls, d, D, rng, n=1, be=None):
