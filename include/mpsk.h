@@ -77,9 +77,10 @@ int mpsk_ctx_workspace_reserve(mpsk_ctx* ctx, size_t bytes);   /* pre-size the p
  * flagged inputs finished by the robust CholeskyQR variant (any pointer may be NULL). */
 int mpsk_ctx_set_qr_mode(mpsk_ctx* ctx, int mode);
 int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallback, long* n_robust);
-/* tsvd algorithm switch: precondition = 1 (default) factors the tall orientation of theta with QRpos first and
- * runs the block-Jacobi iteration on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra),
- * 0 = Jacobi on theta directly.  mpsk_ctx_svd_stats returns the number of Jacobi sweeps of the last mpsk_tsvd. */
+/* tsvd algorithm switch: 0 = Jacobi on theta directly; 1 = the tall orientation of theta is factored with QRpos first and
+ * the block-Jacobi iteration runs on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra); 2 (default)
+ * = additionally R^T = Q1 R1 and the iteration runs on R1^T (mpsk_tsplit only: 15 -> 10 sweeps on graded 4096^2 tensors;
+ * mpsk_tsvd treats 2 as 1).  mpsk_ctx_svd_stats returns the number of Jacobi sweeps of the last mpsk_tsvd / mpsk_tsplit. */
 int mpsk_ctx_set_svd_mode(mpsk_ctx* ctx, int precondition);
 int mpsk_ctx_svd_stats(mpsk_ctx* ctx, int* last_sweeps);
 /* tile override for benchmarking the GEMM core (0,0 restores the heuristic) */
@@ -188,8 +189,9 @@ int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, 
 /* Truncated two-site split theta (m x n, min(m, n) > 64) ~ AL (m x k) . C (k x k) . AR (k x n): what dmrg.jl:96-104 /
  * tdvp.jl:124-126 build from tsvd! (al, c, ar), with the same truncation arguments as mpsk_tsvd, but computed without
  * accumulating the Jacobi rotations (a third less memory traffic per round): AL, AR are isometries to rounding,
- * AL C AR = theta projected on the kept singular subspace, C is triangular (upper if m >= n, lower otherwise) instead
- * of diag(S); S (min(m, n) doubles) receives all singular values, *kept = k.
+ * AL C AR = theta projected on the kept singular subspace, C is TRIANGULAR instead of diag(S) -- lower or upper depending on
+ * the orientation and on the svd mode (mode 2 delivers the left vectors of the tall orientation, the other factor comes from
+ * an LQpos); S (min(m, n) doubles) receives all singular values, *kept = k.
  * Buffers: AL m x min(m,n), C min(m,n)^2, AR min(m,n) x n (only the leading k columns / rows are written). */
 int mpsk_tsplit(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
                 void* AL, int ldal, void* C, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm);

@@ -1,6 +1,8 @@
 # MPSKitROCm.jl -- the reference-side binding of libmpsk (include/mpsk.h).
 #
-# NOT executed in this repository's CI: the build image has no Julia toolchain (DESIGN.md section 1).
+# SKETCH -- never executed: the build image has no Julia toolchain (DESIGN.md section 1).  It documents the ccall
+# signatures and where they hook into the reference; INTEGRATION.md ("What the shim text can and cannot claim") lists
+# what a real integration needs on top (ROCTensor as an AbstractTensorMap or device twins of FiniteMPS / FinEnv).
 # Its executable twin is mpskit.jl_amd/_lib.py + backend.py (ctypes, same argument lists).
 #
 # The reference has no plugin interface; the seams are multiple-dispatch methods (SURVEY.md
@@ -11,7 +13,7 @@
 #   VectorInterface: inner, add!!, scale!!, zerovector, norm    (what KrylovKit needs, quasiparticle_state.jl:357-411)
 module MPSKitROCm
 
-using Libdl, MPSKit, TensorKit, VectorInterface
+using Libdl, LinearAlgebra, MPSKit, TensorKit, VectorInterface
 import MPSKit: MPO_∂∂AC, MPO_∂∂C, MPO_∂∂AC2, transfer_left, transfer_right, SparseMPOSlice
 
 const libmpsk = Ref{String}(get(ENV, "LIBMPSK", "libmpsk.so"))
@@ -33,54 +35,69 @@ function __init__()
     CTX[] = h[]
 end
 
-# ---- device tensor: fp64, column-major, TensorKit index order (include/mpsk.h "Conventions") ----
+# ---- device tensor: fp64 or interleaved complex128, column-major, TensorKit index order (include/mpsk.h "Conventions") ----
 mutable struct ROCTensor{N}
     ptr::Ptr{Cvoid}
     dims::NTuple{N,Int}
-    function ROCTensor(dims::NTuple{N,Int}) where {N}
+    cplx::Bool            # MPSK_C128: (re, im) pairs, the bytes of an Array{ComplexF64}
+    function ROCTensor(dims::NTuple{N,Int}; cplx::Bool=false) where {N}
         p = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:mpsk_malloc, libmpsk[]), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), CTX[], 8 * prod(dims), p))
-        t = new{N}(p[], dims)
+        check(ccall((:mpsk_malloc, libmpsk[]), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), CTX[], (cplx ? 16 : 8) * prod(dims), p))
+        t = new{N}(p[], dims, cplx)
         finalizer(x -> ccall((:mpsk_free, libmpsk[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), CTX[], x.ptr), t)
         return t
     end
 end
 Base.length(t::ROCTensor) = prod(t.dims)
+nreal(t::ROCTensor) = (t.cplx ? 2 : 1) * prod(t.dims)   # doubles behind the pointer: what the vector helpers run over
 
 "upload a trivial-sector TensorMap (its data matrix is already column-major in index order)"
 function ROCTensor(t::AbstractTensorMap)
     a = convert(Array, t)
-    eltype(a) <: Real || all(iszero, imag.(a)) || throw(ArgumentError("MPSK_C128 is reserved; real data only"))
-    d = ROCTensor(size(a))
-    h = Array{Float64}(real.(a))
-    check(ccall((:mpsk_memcpy_h2d, libmpsk[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Csize_t), CTX[], d.ptr, h, sizeof(h)))
+    cx = !(eltype(a) <: Real)
+    d = ROCTensor(size(a); cplx=cx)
+    h = cx ? Array{ComplexF64}(a) : Array{Float64}(a)         # complex: uploaded as is (interleaved = MPSK_C128 layout)
+    check(ccall((:mpsk_memcpy_h2d, libmpsk[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), CTX[], d.ptr, h, sizeof(h)))
     return d
 end
 function Base.Array(d::ROCTensor)
-    h = Array{Float64}(undef, d.dims...)
-    check(ccall((:mpsk_memcpy_d2h, libmpsk[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}, Csize_t), CTX[], h, d.ptr, sizeof(h)))
+    h = d.cplx ? Array{ComplexF64}(undef, d.dims...) : Array{Float64}(undef, d.dims...)
+    check(ccall((:mpsk_memcpy_d2h, libmpsk[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), CTX[], h, d.ptr, sizeof(h)))
     return h
 end
 
 # ---- VectorInterface protocol for KrylovKit (the Krylov loop stays in Julia) ----
+# The vector helpers run over the nreal(x) doubles of a tensor.  For complex tensors `inner` below is Re<x, y> -- what the
+# Hermitian Lanczos solvers of the hot path need (fixedpoint.jl:19-30, integrators.jl:20-25); a general complex inner
+# product needs a second pass (Im<x, y> = <x, J y> with mpsk_vtimes_i) and is left to the integrator.
 VectorInterface.scalartype(::Type{<:ROCTensor}) = Float64
 function VectorInterface.inner(x::ROCTensor, y::ROCTensor)
     out = Ref{Float64}(0)
-    check(ccall((:mpsk_vdot, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), CTX[], length(x), x.ptr, y.ptr, out))
+    check(ccall((:mpsk_vdot, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), CTX[], nreal(x), x.ptr, y.ptr, out))
     return out[]
 end
-function LinearAlgebra_norm(x::ROCTensor)
+function LinearAlgebra.norm(x::ROCTensor)
     out = Ref{Float64}(0)
-    check(ccall((:mpsk_vnrm2, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{Float64}), CTX[], length(x), x.ptr, out))
+    check(ccall((:mpsk_vnrm2, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{Float64}), CTX[], nreal(x), x.ptr, out))
     return out[]
 end
-VectorInterface.zerovector(x::ROCTensor) = (y = ROCTensor(x.dims); check(ccall((:mpsk_vzero, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}), CTX[], length(y), y.ptr)); y)
+VectorInterface.zerovector(x::ROCTensor) = (y = ROCTensor(x.dims; cplx=x.cplx); check(ccall((:mpsk_vzero, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}), CTX[], nreal(y), y.ptr)); y)
+VectorInterface.zerovector!!(x::ROCTensor) = (check(ccall((:mpsk_vzero, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}), CTX[], nreal(x), x.ptr)); x)
+VectorInterface.scale(x::ROCTensor, α::Number) = VectorInterface.scale!!(copy(x), α)
+VectorInterface.scale!(x::ROCTensor, α::Number) = VectorInterface.scale!!(x, α)
+VectorInterface.add(y::ROCTensor, x::ROCTensor, α::Number=1, β::Number=1) = VectorInterface.add!!(copy(y), x, α, β)
+VectorInterface.add!(y::ROCTensor, x::ROCTensor, α::Number=1, β::Number=1) = VectorInterface.add!!(y, x, α, β)
+function Base.copy(x::ROCTensor)
+    y = ROCTensor(x.dims; cplx=x.cplx)
+    check(ccall((:mpsk_vcopy, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}), CTX[], nreal(x), x.ptr, y.ptr))
+    return y
+end
 function VectorInterface.add!!(y::ROCTensor, x::ROCTensor, α::Number=1, β::Number=1)
-    check(ccall((:mpsk_vaxpby, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), CTX[], length(x), Float64(α), x.ptr, Float64(β), y.ptr))
+    check(ccall((:mpsk_vaxpby, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), CTX[], nreal(x), Float64(α), x.ptr, Float64(β), y.ptr))
     return y
 end
 function VectorInterface.scale!!(x::ROCTensor, α::Number)
-    check(ccall((:mpsk_vscal, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}), CTX[], length(x), Float64(α), x.ptr))
+    check(ccall((:mpsk_vscal, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}), CTX[], nreal(x), Float64(α), x.ptr))
     return x
 end
 
@@ -96,24 +113,47 @@ function ROCSlice(H::SparseMPOSlice)
     chil = Int32[dim(H.domspaces[i]) for i in 1:odim]
     chir = Int32[dim(H.imspaces[j]) for j in 1:odim]
     d = dim(H.pspace)
-    kind = zeros(Int32, odim, odim); scal = zeros(Float64, odim, odim)
+    cx = !(scalartype(H) <: Real)                       # MPSK_C128 slice: interleaved complex scalars / blocks
+    kind = zeros(Int32, odim, odim); scal = cx ? zeros(ComplexF64, odim, odim) : zeros(Float64, odim, odim)
     blocks = fill(C_NULL, odim, odim); keep = Any[]
     for (i, j) in keys(H)
         if MPSKit.isscal(H, i, j)
-            kind[i, j] = 1; scal[i, j] = real(H.Os[i, j])
+            kind[i, j] = 1; scal[i, j] = cx ? H.Os[i, j] : real(H.Os[i, j])
         else
-            a = Array{Float64}(real.(convert(Array, H[i, j])))   # [chi_i, d, d, chi_j], column-major
+            a = cx ? Array{ComplexF64}(convert(Array, H[i, j])) : Array{Float64}(real.(convert(Array, H[i, j])))   # [chi_i, d, d, chi_j]
             push!(keep, a); kind[i, j] = 2; blocks[i, j] = pointer(a)
         end
     end
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve keep check(ccall((:mpsk_mposlice_create, libmpsk[]), Cint,
-        (Ptr{Cvoid}, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Int32}, Ptr{Float64}, Ptr{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}),
-        CTX[], 0, odim, chil, chir, d, kind, scal, blocks, h))
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Int32}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}),
+        CTX[], cx ? 1 : 0, odim, chil, chir, d, kind, scal, blocks, h))
     return ROCSlice(h[], d, sum(chil), sum(chir))
 end
 
-# ---- the hot matvec: (h::MPO_∂∂AC)(x)  derivatives.jl:29,77-104 ----
+# ---- the prepared operator: MPO_∂∂AC built once per site visit (derivatives.jl:11-15,44-46), applied per Krylov step ----
+mutable struct ROCddAC <: MPSKit.DerivativeOperator
+    handle::Ptr{Cvoid}
+    leftenv::ROCTensor{3}      # kept alive: mpsk_hac_create does not copy GL / GR
+    rightenv::ROCTensor{3}
+    function ROCddAC(o::ROCSlice, GL::ROCTensor{3}, GR::ROCTensor{3})
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        Dlo, Dl, Dr = GL.dims[2], GL.dims[3], GR.dims[3]
+        check(ccall((:mpsk_hac_create, libmpsk[]), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+            CTX[], o.handle, Dlo, Dl, Dr, GL.ptr, GR.ptr, h))
+        t = new(h[], GL, GR)
+        finalizer(x -> ccall((:mpsk_hac_destroy, libmpsk[]), Cint, (Ptr{Cvoid},), x.handle), t)
+        return t
+    end
+end
+function (h::ROCddAC)(x::ROCTensor{3})
+    y = ROCTensor((h.leftenv.dims[2], x.dims[2], x.dims[3]); cplx=x.cplx)
+    check(ccall((:mpsk_hac_apply, libmpsk[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}), h.handle, x.ptr, 1, y.ptr))
+    return y
+end
+
+# ---- the one-shot matvec: (h::MPO_∂∂AC)(x)  derivatives.jl:29,77-104 ----
 # leftenv / rightenv are ROCTensor{3} of slabs (W, D, D) built by the overloaded transfer_left/right.
 function (h::MPO_∂∂AC{ROCSlice,<:ROCTensor,<:ROCTensor})(x::ROCTensor{3})
     Dl, d, Dr = x.dims
