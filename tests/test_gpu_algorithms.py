@@ -131,7 +131,12 @@ def test_dmrg2_matches_oracle(be):
     po, eo, epso, logo = mo.dmrg2(mo.FiniteMPS(As, normalize=True), Ho, truncdim=D, tol=1e-9, maxiter=6)
     Eg = float(np.sum(mk.expectation_value(pg, Hg, eg)))
     assert max(pg.bond_dims()) <= D
-    assert abs(Eg - logo[-1][1]) <= 1e-8 * abs(Eg)      # truncated two-site sweeps: variational plateau
+    # truncated two-site sweeps, NOT converged after 6 sweeps: the Hubbard chain's bond spectra carry exact multiplets
+    # (SU(2) spin x charge), truncdim = 16 cuts through them and the kept subspace inside a cut multiplet is not unique --
+    # the two runs sit on the same variational plateau to 1e-8, not on the same trajectory.  The sweep-by-sweep bar of
+    # 1e-10 for truncated DMRG2 is held by tests/test_gpu_traces.py (c4_hubbard_L12_D128: truncdim 128 lands between
+    # multiplets on every bond).
+    assert abs(Eg - logo[-1][1]) <= 1e-8 * abs(Eg)
     # with no effective truncation the energies agree to the parity bar (L = 6: max bond 64)
     As = As[:3] + [rng.random((dims[2], 4, 16)), rng.random((16, 4, 4)), rng.random((4, 4, 1))]
     pg, eg, _ = mk.find_groundstate(mk.FiniteMPS(As, normalize=True, be=be), Hg,
