@@ -163,7 +163,20 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when its communicator is created; the contract is ONE JSON line there,
+        # so stdout is pointed at stderr (at the descriptor level: the banner comes from C) until the communicator exists
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            t = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+            dist.all_reduce(t)                      # forces the lazy communicator creation now
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import mpskit_jl_amd as mk
     from mpskit_jl_amd import algorithms as alg, krylov
