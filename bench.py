@@ -214,6 +214,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     be.prof_enable(False)
+    qr_timed = {k: be.qr_stats()[k] - qr0[k] for k in qr0}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=be.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -306,7 +307,7 @@ def main():
             "operator_applications_per_site": args.matvecs,       # the galerkin image reuses the eigensolver's first matvec
             "to_tolerance": to_tol,
             "max_galerkin_last_sweep": None if eps is None else float(max(eps)),
-            "qr_calls_timed": {k: be.qr_stats()[k] - qr0[k] for k in qr0},
+            "qr_calls_timed": qr_timed,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpsk.so")
+# MPSK_LIB: developer override for A/B builds of the SAME library (tools/ab_dac.py); never a fallback
+LIB_PATH = os.environ.get("MPSK_LIB") or os.path.join(_HERE, "libmpsk.so")
 
 
 class MpskError(RuntimeError):

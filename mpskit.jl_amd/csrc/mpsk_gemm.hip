@@ -59,8 +59,12 @@ template <int BMN, bool KCONTIG, bool ALIGNED> struct TileLoader {
       else         { mn = (v % (BMN / 2)) * 2; k = v / (BMN / 2); }
       int gmn = mn0 + mn, gk = k0 + k;
       if (ALIGNED) {
-        const double* p = KCONTIG ? base + gk + (int64_t)gmn * ld : base + gmn + (int64_t)gk * ld;
-        r[i] = *reinterpret_cast<const d2*>(p);
+        // wave-uniform 64-bit base (SGPRs) + loop-invariant 32-bit per-thread byte offset: the loads take the
+        // saddr + voffset form and the k loop carries no 64-bit vector address arithmetic (gemm_f64 only selects the
+        // aligned kernels when 128 * ld * 8 fits 32 bits)
+        const char* ub = reinterpret_cast<const char*>(KCONTIG ? base + k0 + (int64_t)mn0 * ld : base + mn0 + (int64_t)k0 * ld);
+        const uint32_t tob = (KCONTIG ? (uint32_t)k + (uint32_t)mn * (uint32_t)ld : (uint32_t)mn + (uint32_t)k * (uint32_t)ld) * 8u;
+        r[i] = *reinterpret_cast<const d2*>(ub + tob);
       } else {
         d2 t = {0.0, 0.0};
         if (KCONTIG) {
@@ -126,6 +130,19 @@ __device__ __forceinline__ double row_rot(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// Wave-uniform 64-bit load through the scalar cache.  The per-batch K-segment tables (GemmArgs::zsegA / zsegB) are read
+// inside the share loop of the stream-K body, after global stores of the previous share: the compiler can then no longer
+// prove the table unclobbered and falls back to VECTOR loads followed by s_waitcnt vmcnt(0) -- which also drains the
+// prefetched operand tiles (measured: 25 % of the wave cycles of the split-K stage kernel spent in s_waitcnt).
+__device__ __forceinline__ int64_t uniform_load_i64(const int64_t* p) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  const int64_t* sp = reinterpret_cast<const int64_t*>(((uint64_t)hi << 32) | lo);
+  int64_t v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sp));
+  return v;
+}
+
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false, bool CJ = false>
 __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double* __restrict__ Ab,
                                                 const double* __restrict__ Bb, int z, int m0, int n0, int ktb, int kte,
@@ -150,8 +167,8 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
   // per batch from device tables -- uniform scalar loads
   const int64_t* const zsa = ZS ? g.zsegA + (int64_t)z * g.nseg : nullptr;
   const int64_t* const zsb = ZS ? g.zsegB + (int64_t)z * g.nseg : nullptr;
-  auto offA = [&](int sg) -> int64_t { if constexpr (ZS) return zsa[sg]; else return g.segA[sg]; };
-  auto offB = [&](int sg) -> int64_t { if constexpr (ZS) return zsb[sg]; else return g.segB[sg]; };
+  auto offA = [&](int sg) -> int64_t { if constexpr (ZS) return uniform_load_i64(zsa + sg); else return g.segA[sg]; };
+  auto offB = [&](int sg) -> int64_t { if constexpr (ZS) return uniform_load_i64(zsb + sg); else return g.segB[sg]; };
   la.load(Ab + offA(seg), g.lda, m0, kt * BK, g.M, g.K, tid);
   lb.load(Bb + offB(seg), g.ldb, n0, kt * BK, g.N, g.K, tid);
   la.store(sA, tid, CJ ? (int)g.segJ[seg] : 0);
@@ -242,6 +259,130 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
       }
   }
 #endif
+}
+
+// Same contract as gemm_accumulate, with the global loads running TWO k-tiles ahead of the MFMAs (two register sets
+// next to the LDS double buffer).  The 64-wide tiles spend 16 MFMAs (~1000 MFMA-pipe cycles per wave) on a k-tile, so a
+// one-tile prefetch distance only covers the load latency when 4 waves share the SIMD and nothing else is in the way;
+// the PMC pass showed the MFMA pipe busy 72 % of the time at D = 1024 against 81 % with 128x128 tiles (whose k-tile is
+// 4x longer).  The steady-state loop is unrolled by two and free of conditionals: a branch around the loads makes the
+// compiler's s_waitcnt insertion merge the two paths into vmcnt(0), which serialises exactly what this is meant to overlap.
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false, bool CJ = false>
+__device__ __forceinline__ void gemm_accumulate_pf2(const GemmArgs& g, const double* __restrict__ Ab,
+                                                    const double* __restrict__ Bb, int z, int m0, int n0, int ktb, int kte,
+                                                    d4 (&acc)[BM / 32][BN / 32], double* smem) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  using LA = TileLoader<BM, TA, ALIGNED>;
+  using LB = TileLoader<BN, !TB, ALIGNED>;
+  using IA = typename LA::Img;
+  using IB = typename LB::Img;
+  double* const sA = smem;
+  double* const sB = smem + 2 * IA::SIZE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tps = (g.K + BK - 1) / BK;
+  const int64_t* const zsa = ZS ? g.zsegA + (int64_t)z * g.nseg : nullptr;
+  const int64_t* const zsb = ZS ? g.zsegB + (int64_t)z * g.nseg : nullptr;
+  auto offA = [&](int sg) -> int64_t { if constexpr (ZS) return uniform_load_i64(zsa + sg); else return g.segA[sg]; };
+  auto offB = [&](int sg) -> int64_t { if constexpr (ZS) return uniform_load_i64(zsb + sg); else return g.segB[sg]; };
+  LA la0, la1; LB lb0, lb1;
+  int jf0 = 0, jf1 = 0;
+  int segL = ktb / tps, ktL = ktb % tps;          // the next k-tile to be requested from memory
+  const double* pa = Ab + offA(segL);             // segment bases: looked up when the segment changes, not per k-tile
+  const double* pb = Bb + offB(segL);
+  int jfL = CJ ? (int)g.segJ[segL] : 0;
+  auto issue = [&](LA& a, LB& b, int& jf) {
+    a.load(pa, g.lda, m0, ktL * BK, g.M, g.K, tid);
+    b.load(pb, g.ldb, n0, ktL * BK, g.N, g.K, tid);
+    jf = jfL;
+    if (++ktL == tps) {
+      ktL = 0; ++segL;
+      if (segL * tps < kte) {                     // (uniform; scalar loads only: the vmcnt bookkeeping of the two paths agrees)
+        pa = Ab + offA(segL); pb = Bb + offB(segL);
+        if (CJ) jfL = (int)g.segJ[segL];
+      }
+    }
+  };
+  auto compute = [&](const double* __restrict__ a_s, const double* __restrict__ b_s) {
+    double af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = a_s[IA::idx(wm * WTM + i * 16 + fr, fq)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = b_s[IB::idx(wn * WTN + j * 16 + fr, fq)];
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      const int cb = (ks >> 2) & 1, nb = cb ^ 1;
+      if (ks + 4 < BK) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[nb][i] = a_s[IA::idx(wm * WTM + i * 16 + fr, ks + 4 + fq)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[nb][j] = b_s[IB::idx(wn * WTN + j * 16 + fr, ks + 4 + fq)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  double* const sA0 = sA; double* const sA1 = sA + IA::SIZE;
+  double* const sB0 = sB; double* const sB1 = sB + IB::SIZE;
+  issue(la0, lb0, jf0);
+  if (ktb + 1 < kte) issue(la1, lb1, jf1);
+  la0.store(sA0, tid, jf0);
+  lb0.store(sB0, tid);
+  __syncthreads();
+  int t = ktb;
+  // invariant at the top: LDS image 0 holds k-tile t, register set 1 holds (or is receiving) k-tile t + 1
+  while (t + 3 < kte) {
+    issue(la0, lb0, jf0);                          // k-tile t + 2
+    compute(sA0, sB0);
+    la1.store(sA1, tid, jf1);
+    lb1.store(sB1, tid);
+    __syncthreads();
+    issue(la1, lb1, jf1);                          // k-tile t + 3
+    compute(sA1, sB1);
+    la0.store(sA0, tid, jf0);
+    lb0.store(sB0, tid);
+    __syncthreads();
+    t += 2;
+  }
+  const int rem = kte - t;                         // 1, 2 or 3 k-tiles left; nothing beyond t + 1 requested yet
+  if (rem == 3) issue(la0, lb0, jf0);
+  compute(sA0, sB0);
+  if (rem >= 2) {
+    la1.store(sA1, tid, jf1);
+    lb1.store(sB1, tid);
+    __syncthreads();
+    compute(sA1, sB1);
+    if (rem == 3) {
+      la0.store(sA0, tid, jf0);
+      lb0.store(sB0, tid);
+      __syncthreads();
+      compute(sA0, sB0);
+    }
+  }
+  __syncthreads();
+}
+
+// the deep prefetch for every tile but 128x128 (which sits at the 256-VGPR cap and hides the latency behind its 64 MFMAs
+// per k-tile); -DMPSK_PF2=0 builds the one-tile-ahead loop everywhere
+#ifndef MPSK_PF2
+#define MPSK_PF2 1
+#endif
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS, bool CJ>
+__device__ __forceinline__ void gemm_acc_dispatch(const GemmArgs& g, const double* __restrict__ Ab,
+                                                  const double* __restrict__ Bb, int z, int m0, int n0, int ktb, int kte,
+                                                  d4 (&acc)[BM / 32][BN / 32], double* smem) {
+  if constexpr (MPSK_PF2 && !MPSK_MFMA_4X4X4 && BM * BN < 128 * 128)
+    gemm_accumulate_pf2<BM, BN, TA, TB, ALIGNED, ZS, CJ>(g, Ab, Bb, z, m0, n0, ktb, kte, acc, smem);
+  else
+    gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS, CJ>(g, Ab, Bb, z, m0, n0, ktb, kte, acc, smem);
 }
 
 // XCD-ordered linear tile index t -> tile coordinates.  Tiles [x*q, (x+1)*q) run on XCD x (q = ntiles / 8).
@@ -338,7 +479,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   int ktlo = 0, kthi = nt;
   if (g.b_upper) { const int lim = (n0 + BN + BK - 1) / BK; if (lim < kthi) kthi = lim; }
   if (g.a_upper) ktlo = m0 / BK;
-  if (ktlo < kthi) gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS, CJ>(g, Ab, Bb, z, m0, n0, ktlo, kthi, acc, smem);
+  if (ktlo < kthi) gemm_acc_dispatch<BM, BN, TA, TB, ALIGNED, ZS, CJ>(g, Ab, Bb, z, m0, n0, ktlo, kthi, acc, smem);
   gemm_store_c<BM, BN, ALIGNED, CJ>(g, Cb, z, m0, n0, acc);
 }
 
@@ -364,6 +505,16 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
     sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   }
   int u = sid * g.sk_units;
+  int slot = sid;                            // workspace slot == share index in the (tile, k) order the fixup walks
+  if (g.sk_split_major) {
+    // split-K launches (sk_units divides KT): shares ordered split-major, so that the 128 workgroups resident on one XCD
+    // are 128 DIFFERENT tiles at the SAME k position (a 16 x 8 tile rectangle whose A / B panels its L2 streams once)
+    // instead of 64 tiles at two k positions that share nothing
+    const int TZ = ntiles * g.batch;
+    const int split = sid / TZ, tzs = sid - split * TZ;
+    u = tzs * KT + split * g.sk_units;
+    slot = tzs * (KT / g.sk_units) + split;
+  }
   const int uend = (u + g.sk_units < U) ? u + g.sk_units : U;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave & 1, wn = wave >> 1, fr = lane & 15, fq = lane >> 4;
@@ -387,12 +538,12 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
       int ka = kt0, kb = kt1;                 // triangular operands: clamp the share to the structurally non-zero k-tiles
       if (g.b_upper) { const int lim = (n0 + BN + BK - 1) / BK; if (lim < kb) kb = lim; }
       if (g.a_upper) { const int lo = m0 / BK; if (lo > ka) ka = lo; }
-      if (ka < kb) gemm_accumulate<BM, BN, TA, TB, ALIGNED, ZS>(g, Ab, Bb, z, m0, n0, ka, kb, acc, smem);
+      if (ka < kb) gemm_acc_dispatch<BM, BN, TA, TB, ALIGNED, ZS, false>(g, Ab, Bb, z, m0, n0, ka, kb, acc, smem);
     }
     // one epilogue for both destinations (uniform parameters): C tile (kt0 == 0) or workspace slot
     const bool toC = (kt0 == 0);
     double* base = toC ? g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC) + m0 + (int64_t)n0 * g.ldc
-                       : g.sk_ws + (int64_t)sid * BM * BN;
+                       : g.sk_ws + (int64_t)slot * BM * BN;
     const int64_t ld = toC ? g.ldc : BM;
     const double beta = toC ? g.beta : 0.0;
     const double alpha = g.alpha;
@@ -420,17 +571,21 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
   }
 }
 
+// waves per SIMD the register allocation has to leave room for: 4 for the 64x64 tile (<= 128 VGPRs; its LDS images allow
+// 4 workgroups per CU and the deep prefetch relies on them), 2 otherwise
+constexpr int min_waves(int bm, int bn) { return (bm == 64 && bn == 64) ? 4 : 2; }
+
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_sk_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, min_waves(BM, BN)) void gemm_sk_f64_kernel(GemmArgs g) {
   gemm_sk_body<BM, BN, TA, TB, ALIGNED>(g);
 }
 template <int BM, int BN, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_sk_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, min_waves(BM, BN)) void dac_gemm_sk_f64_kernel(GemmArgs g) {
   gemm_sk_body<BM, BN, false, false, ALIGNED>(g);
 }
 // per-batch K-segment tables (stage 3 of the prepared operator, mpsk_hac_apply)
 template <int BM, int BN, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_sk_zs_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, min_waves(BM, BN)) void dac_gemm_sk_zs_f64_kernel(GemmArgs g) {
   gemm_sk_body<BM, BN, false, false, ALIGNED, true>(g);
 }
 
@@ -482,7 +637,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs g) {
 }
 
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, min_waves(BM, BN)) void gemm_f64_kernel(GemmArgs g) {
   gemm_body<BM, BN, TA, TB, ALIGNED>(g);
 }
 
@@ -490,17 +645,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g) {
 // (dAC / dC / dAC2): rocprofv3 --stats and the in-library event profile then report the hot kernel
 // separately from the small gauge-step GEMMs.
 template <int BM, int BN, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, min_waves(BM, BN)) void dac_gemm_f64_kernel(GemmArgs g) {
   gemm_body<BM, BN, false, false, ALIGNED>(g);
 }
 template <int BM, int BN, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void dac_gemm_zs_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, min_waves(BM, BN)) void dac_gemm_zs_f64_kernel(GemmArgs g) {
   gemm_body<BM, BN, false, false, ALIGNED, true>(g);
 }
 
 // complex128 family (A / C rows interleaved re-im, B planar; GemmArgs::segJ / c_rs): same body with the J-aware loader
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
-__global__ __launch_bounds__(NTHREADS, 2) void cgemm_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, min_waves(BM, BN)) void cgemm_f64_kernel(GemmArgs g) {
   gemm_body<BM, BN, TA, TB, ALIGNED, false, true>(g);
 }
 
@@ -697,6 +852,7 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   choose_tile(g.M, g.N, g.K * g.nseg, g.batch, &bm, &bn);
   g.sk_units = 0;
   g.sk_ws = nullptr;
+  g.sk_split_major = 0;
   if (g.cplx && g.c_rs == 0) g.c_rs = 1;
   if (g.upper_only && g.M != g.N) g.upper_only = 0;
   if (g.nseg != 1 || g.transA || g.transB) g.a_upper = g.b_upper = 0;
@@ -726,7 +882,7 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
       while (f > 1 && KT / f < 16) --f;
       if (f >= 2) {
         double* ws = sk_workspace(s);
-        if (ws) { g.sk_units = (KT + f - 1) / f; g.sk_ws = ws; }
+        if (ws) { g.sk_units = (KT + f - 1) / f; g.sk_ws = ws; g.sk_split_major = (KT % g.sk_units == 0) ? 1 : 0; }
       }
     }
   }
@@ -747,7 +903,8 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
   }
   bool aligned = (g.M % bm == 0) && (g.N % bn == 0) && (g.K % BK == 0) && (g.lda % 2 == 0) &&
                  (g.ldb % 2 == 0) && (g.bsA % 2 == 0) && (g.bsB % 2 == 0) &&
-                 ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
+                 ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) &&
+                 g.lda < ((int64_t)1 << 21) && g.ldb < ((int64_t)1 << 21);   // 32-bit per-thread byte offsets
   if (g.tabA || g.tabB || g.zsegA || g.zsegB) aligned = aligned && g.tabs_even;
   if (!g.zsegA) for (int i = 0; i < g.nseg && i < MAXSEG; ++i) aligned = aligned && (g.segA[i] % 2 == 0);
   if (!g.zsegB) for (int i = 0; i < g.nseg && i < MAXSEG; ++i) aligned = aligned && (g.segB[i] % 2 == 0);

@@ -47,6 +47,7 @@ struct GemmArgs {
   int splitN;
   // stream-K (set by gemm_f64 itself): units of k-tiles per workgroup and the partial-tile workspace
   int sk_units;
+  int sk_split_major;   // split-K launches: share index = split * (tiles * batch) + tile (see gemm_sk_body)
   double* sk_ws;
   // XCD grid (set by gemm_f64): the 8 XCDs' tile chunks are xcd_gx x xcd_gy rectangles of the tile grid (0: linear)
   int xcd_gx, xcd_gy;
