@@ -267,6 +267,9 @@ __device__ __forceinline__ void gemm_accumulate(const GemmArgs& g, const double*
 // the PMC pass showed the MFMA pipe busy 72 % of the time at D = 1024 against 81 % with 128x128 tiles (whose k-tile is
 // 4x longer).  The steady-state loop is unrolled by two and free of conditionals: a branch around the loads makes the
 // compiler's s_waitcnt insertion merge the two paths into vmcnt(0), which serialises exactly what this is meant to overlap.
+#ifndef MPSK_MID_KS
+#define MPSK_MID_KS 8      // k-step (0, 4, 8, 12) behind whose MFMA group the next tile's LDS writes are issued
+#endif
 template <int BM, int BN, bool TA, bool TB, bool ALIGNED, bool ZS = false, bool CJ = false>
 __device__ __forceinline__ void gemm_accumulate_pf2(const GemmArgs& g, const double* __restrict__ Ab,
                                                     const double* __restrict__ Bb, int z, int m0, int n0, int ktb, int kte,
@@ -306,7 +309,7 @@ __device__ __forceinline__ void gemm_accumulate_pf2(const GemmArgs& g, const dou
       }
     }
   };
-  auto compute = [&](const double* __restrict__ a_s, const double* __restrict__ b_s) {
+  auto compute = [&](const double* __restrict__ a_s, const double* __restrict__ b_s, auto&& mid) {
     double af[2][TM], bf[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[0][i] = a_s[IA::idx(wm * WTM + i * 16 + fr, fq)];
@@ -328,8 +331,13 @@ __device__ __forceinline__ void gemm_accumulate_pf2(const GemmArgs& g, const dou
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // the LDS image of the NEXT k-tile is written behind the first MFMA group (its registers arrived a phase ago, the
+      // buffer was released by the barrier that ended the previous phase): the writes and their swizzle moves issue
+      // while the matrix pipe works instead of in a serial tail before the barrier
+      if (ks == MPSK_MID_KS) { mid(); __builtin_amdgcn_sched_barrier(0); }
     }
   };
+  auto none = [] {};
   double* const sA0 = sA; double* const sA1 = sA + IA::SIZE;
   double* const sB0 = sB; double* const sB1 = sB + IB::SIZE;
   issue(la0, lb0, jf0);
@@ -341,30 +349,26 @@ __device__ __forceinline__ void gemm_accumulate_pf2(const GemmArgs& g, const dou
   // invariant at the top: LDS image 0 holds k-tile t, register set 1 holds (or is receiving) k-tile t + 1
   while (t + 3 < kte) {
     issue(la0, lb0, jf0);                          // k-tile t + 2
-    compute(sA0, sB0);
-    la1.store(sA1, tid, jf1);
-    lb1.store(sB1, tid);
+    compute(sA0, sB0, [&] { la1.store(sA1, tid, jf1); lb1.store(sB1, tid); });
     __syncthreads();
     issue(la1, lb1, jf1);                          // k-tile t + 3
-    compute(sA1, sB1);
-    la0.store(sA0, tid, jf0);
-    lb0.store(sB0, tid);
+    compute(sA1, sB1, [&] { la0.store(sA0, tid, jf0); lb0.store(sB0, tid); });
     __syncthreads();
     t += 2;
   }
   const int rem = kte - t;                         // 1, 2 or 3 k-tiles left; nothing beyond t + 1 requested yet
   if (rem == 3) issue(la0, lb0, jf0);
-  compute(sA0, sB0);
+  compute(sA0, sB0, none);
   if (rem >= 2) {
     la1.store(sA1, tid, jf1);
     lb1.store(sB1, tid);
     __syncthreads();
-    compute(sA1, sB1);
+    compute(sA1, sB1, none);
     if (rem == 3) {
       la0.store(sA0, tid, jf0);
       lb0.store(sB0, tid);
       __syncthreads();
-      compute(sA0, sB0);
+      compute(sA0, sB0, none);
     }
   }
   __syncthreads();
@@ -513,7 +517,7 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
     const int TZ = ntiles * g.batch;
     const int split = sid / TZ, tzs = sid - split * TZ;
     u = tzs * KT + split * g.sk_units;
-    slot = tzs * (KT / g.sk_units) + split;
+    slot = tzs * (KT / g.sk_units - 1) + split - 1;      // compact: the first share of a tile writes C, not a slot
   }
   const int uend = (u + g.sk_units < U) ? u + g.sk_units : U;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs g) {
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
         const int e = e0 + 256 * q;
-        if (e < BM * BN) sacc[q] += g.sk_ws[(int64_t)w * BM * BN + e];
+        if (e < BM * BN) sacc[q] += g.sk_ws[(int64_t)(g.sk_split_major ? w - tz - 1 : w) * BM * BN + e];
       }
     }
 #pragma unroll
@@ -784,19 +788,25 @@ static hipError_t launch_tile(const GemmArgs& g, int bm, int bn, hipStream_t s) 
   return launch_cfg<64, 64, TA, TB, ALIGNED>(g, s);
 }
 
-// Tile choice (measured on MI355X, tools/bench_dac.py): the largest tile that still yields >= 6
-// workgroups per CU wins (D = 2048: 128x128, 62 TF); below that, smaller tiles balance the 256 CUs
-// better and run 4 waves/SIMD (D = 1024: 64x64 53 TF vs 128x128 35 TF).
+// Tile choice (measured on MI355X, tools/ab_dac.py, whole prepared-operator matvec in TFLOP/s after the deep-prefetch /
+// interleaved-store rework of the 64-wide loop):
+//     D      64x64   128x64   128x128          (stage 1: M = D, N = 2D, K = D, batch 5 -> 64x64-tile count T64)
+//   1024     65.2     58.9     --              T64 =  2 560
+//   2048     66.2     65.4     64.2            T64 = 10 240
+//   3072     63.7     65.7     60.2            T64 = 23 040
+//   4096     60.9     65.5     64.8            T64 = 40 960
+// The small tile wins while its extra operand traffic (twice the panel re-reads of 128x128) stays inside the L2 / MALL;
+// beyond that the wider tile's reuse pays.  128x128 (227 VGPRs, no room for the second prefetch set) is no longer chosen
+// by default; MPSK_STREAMK=1 and mpsk_ctx_force_tile still reach it.
 static void choose_tile(int M, int N, int K, int batch, int* bm, int* bn) {
   // short-K products (the tall-skinny Jacobi updates X_p W_p: K = 64 = 4 k-tiles) never reach the steady state of the
   // pipeline: the smallest tile gives the most workgroups to hide the prologue (tools/svd_tiles.py: -2.5 % on a 4096^2 split)
-  if (K <= 4 * BK) { *bm = 64; *bn = 64; return; }
-  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-  for (int c = 0; c < 4; ++c) {
-    if ((M <= 64 && cand[c][0] > 64) || (N <= 64 && cand[c][1] > 64)) continue;   // never pad a 64-wide side to 128
-    int64_t tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
-    if (tm * tn * batch >= 6 * 256 || c == 3) { *bm = cand[c][0]; *bn = cand[c][1]; return; }
-  }
+  *bm = 64; *bn = 64;
+  if (K <= 4 * BK) return;
+  const int64_t T64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch;
+  if (T64 <= 16384 && (M < 3072 || N < 3072)) return;     // (stage 3 at D >= 3072: few tiles, but 10 D deep)
+  if (M > 64) *bm = 128;                                   // never pad a 64-wide side to 128
+  else if (N > 64) *bn = 128;
 }
 
 static std::atomic<int> g_force_bm{0}, g_force_bn{0};   // benchmarking knob (process-wide)
@@ -809,6 +819,7 @@ static std::atomic<bool> g_sk_enabled{(getenv("MPSK_STREAMK") != nullptr) && (ge
 void gemm_enable_streamk(bool on) { g_sk_enabled = on; }
 static bool g_xcd_grid_enabled = (getenv("MPSK_XCDGRID") == nullptr) || (getenv("MPSK_XCDGRID")[0] != '0');
 static bool g_splitk_enabled = (getenv("MPSK_SPLITK") == nullptr) || (getenv("MPSK_SPLITK")[0] != '0');
+static int g_splitk_force = getenv("MPSK_SPLITK_F") ? atoi(getenv("MPSK_SPLITK_F")) : 0;
 constexpr size_t SK_WS_DOUBLES = (size_t)1024 * 128 * 128 / 2;   // 512 slots of 128x128 == 2048 slots of 64x64
 // partial-tile workspace: one per (device, stream) so that concurrent streams never share slots (launches on ONE
 // stream are ordered, so ctxs that share a stream may share its slots); allocated on first use (64 MiB each), freed by
@@ -873,16 +884,38 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
     // (the fixed-order fixup is a second, dependent launch of ~18 us: below ~64 k-tiles the split loses.  An
     //  in-kernel fixup by the last-arriving share was measured and rejected: its agent-scope release/acquire
     //  fences write back / invalidate the XCD's L2 and cost 45 % on the big dAC stage.)
-    if (g.sk_units == 0 && g_splitk_enabled && bm == 64 && bn == 64 && Ts <= 512 && KT >= 64) {
-      // split-K for long-K GEMMs with too few 64x64 tiles to fill the chip (<= 2 workgroups per CU):
-      // f shares per tile through the stream-K body (first share writes C, the others a workspace
-      // slot, fixed-order fixup).  E.g. stage 3 of dAC at D = 1024: 512 tiles x 320 k-tiles -> f = 2.
-      int f = (int)(1024 / Ts);
-      if (f > 8) f = 8;
-      while (f > 1 && KT / f < 16) --f;
-      if (f >= 2) {
+    if (g.sk_units == 0 && g_splitk_enabled && bm == 64 && bn == 64 && KT >= 64 && Ts <= 4096) {
+      // split-K for long-K GEMMs whose 64x64 tile count does not balance the 256 CUs: f shares per tile through the
+      // stream-K body (first share writes C, the others a workspace slot, fixed-order fixup).  Model of the launch, in
+      // k-tile times: the busiest CU runs n = ceil(Ts f / 256) shares of KT / f + 6 (prologue / epilogue) each, four at a
+      // time, plus 3 per extra share for its partial tile and 12 for the fixup pass.  Measured (tools/ab_dac.py with
+      // MPSK_SPLITK_F, stage 3 in us for f = 1 / 2 / 4): D = 1024: 352 / 340 / 347, D = 1536: 1239 / 1119 / 1118,
+      // D = 768: 262 / 198 / 176, D = 512: 109 / 67 / 63.
+      const int64_t slots = (int64_t)(SK_WS_DOUBLES / (64 * 64));
+      int best_f = 1;
+      double best = 0.0;
+      for (int f = 1; f <= 8; ++f) {
+        if (f > 1 && (KT / f < 16 || Ts * (f - 1) > slots)) break;
+        const int64_t n = (Ts * f + 255) / 256;          // shares on the busiest CU; 4 run at a time
+        const int r = (int)(n % 4);                      // the last, partial group shares the matrix pipes r ways:
+        const double phi[4] = {1.0, 0.55, 0.92, 0.98};   // measured pipe utilisation with 1 / 2 / 3 resident workgroups
+        const double len = (double)KT / f + 6.0;
+        const double cost = (double)(n - r) * len + (r ? r * len / phi[r] : 0.0) + 3.0 * (f - 1) * (double)n / f + (f > 1 ? 12.0 : 0.0);
+        if (f == 1 || cost < 0.97 * best) { best = cost; best_f = f; }
+      }
+      if (g_splitk_force > 0 && (g_splitk_force == 1 || (KT / g_splitk_force >= 16 && Ts * (g_splitk_force - 1) <= slots)))
+        best_f = g_splitk_force;                // MPSK_SPLITK_F: tuning knob
+      if (best_f >= 2) {
         double* ws = sk_workspace(s);
-        if (ws) { g.sk_units = (KT + f - 1) / f; g.sk_ws = ws; g.sk_split_major = (KT % g.sk_units == 0) ? 1 : 0; }
+        if (ws) {
+          g.sk_units = (KT + best_f - 1) / best_f;
+          g.sk_ws = ws;
+          g.sk_split_major = (KT % g.sk_units == 0 && KT / g.sk_units == best_f) ? 1 : 0;
+          if (!g.sk_split_major) {          // uneven shares: logical share index == slot index, needs one slot per share
+            const int64_t U = Ts * KT;
+            if ((U + g.sk_units - 1) / g.sk_units > slots) { g.sk_units = 0; g.sk_ws = nullptr; }
+          }
+        }
       }
     }
   }

@@ -8,6 +8,8 @@ def flops_dAC(D, d, W):
     return 2 * W * D * D * d * D + 2 * W * W * d * d * D * D + 2 * W * D * d * D * D
 
 be = mk.Backend(0)
+if os.environ.get('AB_TILE'):
+    be.lib.mpsk_ctx_force_tile(be.ctx, *[int(v) for v in os.environ['AB_TILE'].split(',')])
 W = 5
 for a in (sys.argv[1:] or ["1024,2"]):
     D, d = (int(v) for v in a.split(","))
