@@ -251,10 +251,13 @@ def main():
         x = mk.DTensor(torch.rand(D * d * D, dtype=torch.float64, device=be.device), (D, d, D))
         y = be.empty(D, d, D)
         hop = mk.MPO_ddAC(be, H[0], GL, GR)         # what the sweep applies: prepared once per site, then applied
-        for _ in range(3):
+        # ~70 ms of warm-up: the event read-back above leaves the GPU idle long enough for its clocks to drop, and the
+        # first ~50 ms of matvecs after an idle period run 15 % slower (0.764 ms per matvec in the first batch of 20 after
+        # an idle period, 0.662 ms in every later one)
+        for _ in range(100):
             hop(x, out=y)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        nrep = 20
+        nrep = 50
         e0.record()
         for _ in range(nrep):
             hop(x, out=y)

@@ -16,7 +16,8 @@ for a in (sys.argv[1:] or ["1024,2"]):
     H = mk.heisenberg_XXX(0.5 if d == 2 else 1.0, be=be)
     r = lambda *s: mk.DTensor(torch.rand(*s, dtype=torch.float64, device=be.device).flatten(), s)
     GL, GR, x, y = r(W, D, D), r(W, D, D), r(D, d, D), be.empty(D, d, D)
-    h = mk.MPO_ddAC(be, H[1], GL, GR)
+    h = mk.MPO_ddAC(be, H[int(os.environ.get("AB_SITE", "1"))], GL, GR)
+    print("   hac", h._hac.info() if getattr(h, "_hac", None) else None)
     for _ in range(5):
         h(x, out=y)
     torch.cuda.synchronize()
