@@ -229,8 +229,14 @@ int mpsk_vorth_step(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void
 /* the same step without a host synchronisation: the 2k+1 scalars (h1[k], h2[k], |remainder|^2; h = h1 + h2,
  * beta = sqrt of the last) stay in dev_out (device memory, >= 2k+1 doubles) */
 int mpsk_vorth_step_dev(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* y, void* dev_out);
-/* y = sum_j coefs[j] xs[j]   (Ritz vector assembly) */
+/* y = sum_j coefs[j] xs[j]   (Ritz vector assembly); asynchronous (host_coefs is copied before the call returns) */
 int mpsk_vlincomb(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y);
+/* y = x / |x| (y may be x) and dev_out[0] = |x|^2, both without a host synchronisation: the start / Ritz-vector
+ * normalisations of a fixed-budget Krylov solve and the per-site galerkin norms of a sweep are read back once per
+ * solve / sweep instead of stalling the stream at every use (normalize! in toolbox.jl:18, fixedpoint.jl:19-30).
+ * dev_n2 (optional, device memory, one double) receives |x|^2. */
+int mpsk_vnormalize_dev(mpsk_ctx* ctx, int64_t n, const void* x, void* y, void* dev_n2);
+int mpsk_vnrm2_dev(mpsk_ctx* ctx, int64_t n, const void* x, void* dev_out);
 
 #ifdef __cplusplus
 }

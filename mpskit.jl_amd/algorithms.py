@@ -88,15 +88,23 @@ def fixedpoint(be, A, x0, alg: Arnoldi, ws=None, first_image=None):
 
 # ---- measurements ------------------------------------------------------------------------------
 
-def _galerkin(be, h, ac, al, g=None):
+def _galerkin(be, h, ac, al, g=None, slot=None, offset=0):
     """|| (1 - AL AL^dag) normalize(h(AC)) ||  for explicit tensors.
-    g: h(AC) up to a positive factor if the caller already has it (the eigensolver's first matvec)."""
+    g: h(AC) up to a positive factor if the caller already has it (the eigensolver's first matvec).
+    slot: device buffer that receives the SQUARED result at `offset` instead of a host read-back (the sweep collects its
+    2L - 2 values with one download at the end); the return value is then None."""
     g = h(ac) if g is None else g
-    be.scal(1.0 / be.norm(g), g)
+    if hasattr(be, "normalize_dev"):
+        be.normalize_dev(g)
+    else:
+        be.scal(1.0 / be.norm(g), g)
     Dl, d, Dr = al.shape
     alm, gm = al.reshape(Dl * d, Dr), g.reshape(Dl * d, g.shape[2])
     t = be.gemm(alm, gm, transA=True)
     be.gemm(alm, t, alpha=-1.0, beta=1.0, out=gm)
+    if slot is not None:
+        be.nrm2_dev(gm, slot, offset)
+        return None
     return be.norm(gm)
 
 
@@ -184,8 +192,12 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
     the blocked layout together with `encode` / `decode` (rows <-> rank blocks, once per site visit)."""
     be = psi.be
     L = len(psi)
+    visits = list(range(0, L - 1)) + list(range(L - 1, 0, -1))
+    # galerkin norms stay on the device until the sweep is over (one read-back instead of two stream stalls per site)
+    defer = hasattr(be, "nrm2_dev")
+    gslot = (ws if ws is not None else krylov.KrylovWorkspace(be)).get((len(visits), 1), 1)[0] if defer else None   # (2-D key: never the solver's 1-D slot)
     eps_s = [0.0] * L
-    for pos in list(range(0, L - 1)) + list(range(L - 1, 0, -1)):
+    for iv, pos in enumerate(visits):
         h = envs.site_op(pos, psi) if hasattr(envs, "site_op") else ddAC(pos, psi, H, envs)
         ac_old = psi.AC(pos)
         enc = getattr(h, "encode", None)
@@ -206,7 +218,13 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
             # and gauged lazily when the next site asks for AR[pos] (orthoview.jl:27-31, 49-54)
             al_old = psi.AL(pos)
             psi.set_AC(pos, vec)
-        eps_s[pos] = max(eps_s[pos], _galerkin(be, h, ac_old, al_old, g))
+        e = _galerkin(be, h, ac_old, al_old, g, gslot, iv)
+        if not defer:
+            eps_s[pos] = max(eps_s[pos], e)
+    if defer:
+        vals = np.sqrt(np.maximum(np.asarray(be.download(gslot)).reshape(-1), 0.0))
+        for iv, pos in enumerate(visits):
+            eps_s[pos] = max(eps_s[pos], float(vals[iv]))
     return eps_s
 
 

@@ -492,6 +492,17 @@ class Backend:
         check(self.lib.mpsk_vorth_step_dev(self.ctx, y.size, len(xs), self._ptrs(xs), y.ptr, slot.ptr + 8 * offset),
               "mpsk_vorth_step_dev")
 
+    def normalize_dev(self, x: DTensor, out: DTensor = None, slot: DTensor = None, offset: int = 0):
+        """out = x / |x| (default in place) with no host sync; |x|^2 goes to slot[offset] (device) when given."""
+        y = x if out is None else out
+        check(self.lib.mpsk_vnormalize_dev(self.ctx, x.size, x.ptr, y.ptr, None if slot is None else slot.ptr + 8 * offset),
+              "mpsk_vnormalize_dev")
+        return y
+
+    def nrm2_dev(self, x: DTensor, slot: DTensor, offset: int = 0):
+        """slot[offset] = |x|^2 on the device, no host sync."""
+        check(self.lib.mpsk_vnrm2_dev(self.ctx, x.size, x.ptr, slot.ptr + 8 * offset), "mpsk_vnrm2_dev")
+
     def lincomb(self, xs, coefs, out: DTensor = None):
         y = self.empty(xs[0].shape) if out is None else out
         cf = (C.c_double * len(xs))(*[float(c) for c in coefs])

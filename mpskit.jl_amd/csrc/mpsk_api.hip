@@ -58,6 +58,10 @@ struct mpsk_ctx {
   double* d_scal = nullptr;     // [MAXK] device scalars
   double* d_partial = nullptr;  // dot scratch
   double* h_scal = nullptr;     // pinned host mirror
+  double* d_coef = nullptr;     // [MAXK] coefficients of mpsk_vlincomb + their pinned source + the event that frees it
+  double* h_coef = nullptr;
+  hipEvent_t ev_coef = nullptr;
+  bool coef_pending = false;
   int dtype = MPSK_F64;         // scalar type of the slice-less entry points (mpsk_ctx_set_dtype)
   int last_svd_sweeps = 0;
   int svd_precondition = 2;     // mpsk_ctx_set_svd_mode: 0 plain, 1 QR-preconditioned, 2 QR + QR of R^T (mpsk_tsplit; mpsk_tsvd treats it as 1)
@@ -86,6 +90,8 @@ struct mpsk_hac {
   int mode;                     // 0: GEMM -> slab mix -> GEMM (mpsk_dAC);  1: right-combined environment, no mix
   double* GRc = nullptr;        // [nc + 1][Dr, Dr]   (last slab: zeros, pads the shorter segment lists)
   int64_t* zseg = nullptr;      // device [2][d][nseg]: A offsets (into T1), B offsets (into GRc)
+  std::vector<int64_t> zseg_host;   // source of the asynchronous upload of zseg: lives as long as the handle (no sync)
+  hipEvent_t ev_up = nullptr;       // completion of that upload (waited for before the handle is freed)
   int pool_idx = -1;
 };
 constexpr int MAXK = 256;
@@ -110,6 +116,9 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
   HIPCHK(hipMalloc(&c->d_scal, sizeof(double) * MAXK));
   HIPCHK(hipMalloc(&c->d_partial, sizeof(double) * MPSK_DOT_SCRATCH));
   HIPCHK(hipHostMalloc(&c->h_scal, sizeof(double) * MAXK, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&c->d_coef, sizeof(double) * MAXK));
+  HIPCHK(hipHostMalloc(&c->h_coef, sizeof(double) * MAXK, hipHostMallocDefault));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_coef, hipEventDisableTiming));
   HIPCHK(hipMalloc(&c->d_flag, 64));
   HIPCHK(hipHostMalloc(&c->h_flags, 64, hipHostMallocDefault));
   HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -132,6 +141,9 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->d_scal) (void)hipFree(c->d_scal);
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->d_coef) (void)hipFree(c->d_coef);
+  if (c->h_coef) (void)hipHostFree(c->h_coef);
+  if (c->ev_coef) (void)hipEventDestroy(c->ev_coef);
   if (c->d_flag) (void)hipFree(c->d_flag);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->ws2) (void)hipFree(c->ws2);
@@ -680,7 +692,11 @@ int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr
     if (int rc = pool_take(c, sizeof(double) * 2 * ev2(nG), &buf, &h->pool_idx)) { delete h; return rc; }
     h->GRc = (double*)buf;
     hipError_t e = cx_planes((const double*)GR, nG, h->GRc, h->GRc + ev2(nG), c->stream);
-    if (e != hipSuccess) { c->pool[h->pool_idx].used = false; delete h; return fail(MPSK_ERR_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(c->stream);
+      if (h->ev_up) (void)hipEventDestroy(h->ev_up);
+      c->pool[h->pool_idx].used = false; delete h; return fail(MPSK_ERR_HIP, hipGetErrorString(e));
+    }
     *out = h;
     return MPSK_OK;
   }
@@ -698,7 +714,8 @@ int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr
     if (e == hipSuccess) e = hipMemsetAsync(h->GRc + slabR * nc, 0, sizeof(double) * slabR, c->stream);
     // segment tables: stage-3 batch z = t;  A offset into T1 (slab w, plane s), B offset into GRc (slab c)
     const size_t slab1 = (size_t)Dlo * d * Dr;
-    std::vector<int64_t> tab((size_t)2 * d * ns);
+    h->zseg_host.assign((size_t)2 * d * ns, 0);
+    std::vector<int64_t>& tab = h->zseg_host;
     for (int t = 0; t < d; ++t) {
       int k = 0;
       for (int ci = 0; ci < nc; ++ci)
@@ -710,7 +727,8 @@ int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr
       for (; k < ns; ++k) { tab[(size_t)t * ns + k] = 0; tab[(size_t)(d + t) * ns + k] = (int64_t)nc * slabR; }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h->zseg, tab.data(), sizeof(int64_t) * tab.size(), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // `tab` is a host temporary
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(h->ev_up, c->stream);
     if (e != hipSuccess) { c->pool[h->pool_idx].used = false; delete h; return fail(MPSK_ERR_HIP, hipGetErrorString(e)); }
   }
   *out = h;
@@ -720,6 +738,7 @@ int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr
 int mpsk_hac_destroy(mpsk_hac* h) {
   if (!h) return MPSK_OK;
   if (h->pool_idx >= 0 && h->pool_idx < (int)h->ctx->pool.size()) h->ctx->pool[h->pool_idx].used = false;
+  if (h->ev_up) { (void)hipEventSynchronize(h->ev_up); (void)hipEventDestroy(h->ev_up); }   // zseg_host is still being read until then
   delete h;
   return MPSK_OK;
 }
@@ -1334,13 +1353,38 @@ int mpsk_vlincomb(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const do
   REQUIRE(c && xs && y && host_coefs, "NULL argument");
   REQUIRE(k > 0 && k <= MAXK && n > 0, "bad k or n");
   HIPCHK(hipSetDevice(c->device));
-  // coefficients travel through the pinned mirror; sync first so a previous fetch is not clobbered
-  HIPCHK(hipStreamSynchronize(c->stream));
-  std::memcpy(c->h_scal, host_coefs, sizeof(double) * k);
-  HIPCHK(hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+  // asynchronous: the coefficients travel through their own pinned buffer, which is only rewritten once the upload that
+  // last read it has completed (an event wait, normally already satisfied) -- no stream synchronisation on either side
+  if (c->coef_pending) { HIPCHK(hipEventSynchronize(c->ev_coef)); c->coef_pending = false; }
+  std::memcpy(c->h_coef, host_coefs, sizeof(double) * k);
+  HIPCHK(hipMemcpyAsync(c->d_coef, c->h_coef, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->ev_coef, c->stream));
+  c->coef_pending = true;
   HIPCHK(hipMemsetAsync(y, 0, sizeof(double) * n, c->stream));
-  HIPCHK(vec_multiaxpy((const double* const*)xs, c->d_scal, k, 1.0, (double*)y, n, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(vec_multiaxpy((const double* const*)xs, c->d_coef, k, 1.0, (double*)y, n, c->stream));
+  return MPSK_OK;
+}
+
+// y = x / |x| without a host synchronisation; |x|^2 is left in dev_n2 (device memory, one double) when given
+int mpsk_vnormalize_dev(mpsk_ctx* c, int64_t n, const void* x, void* y, void* dev_n2) {
+  REQUIRE(c && x && y, "NULL argument");
+  REQUIRE(n > 0, "bad n");
+  HIPCHK(hipSetDevice(c->device));
+  double* n2 = dev_n2 ? (double*)dev_n2 : c->d_scal + (MAXK - 1);
+  const double* xs[1] = {(const double*)x};
+  HIPCHK(vec_multidot(xs, 1, (const double*)x, n, n2, c->d_partial, c->stream));
+  if (y != x) HIPCHK(hipMemcpyAsync(y, x, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(vec_scal_rsqrt_dev(n2, (double*)y, n, c->stream));
+  return MPSK_OK;
+}
+
+// dev_out[0] = |x|^2 (device memory), no host synchronisation
+int mpsk_vnrm2_dev(mpsk_ctx* c, int64_t n, const void* x, void* dev_out) {
+  REQUIRE(c && x && dev_out, "NULL argument");
+  REQUIRE(n > 0, "bad n");
+  HIPCHK(hipSetDevice(c->device));
+  const double* xs[1] = {(const double*)x};
+  HIPCHK(vec_multidot(xs, 1, (const double*)x, n, (double*)dev_out, c->d_partial, c->stream));
   return MPSK_OK;
 }
 

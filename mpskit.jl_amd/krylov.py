@@ -51,8 +51,7 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         m = max(1, min(fixed_matvecs, x0.size))
         stride = 2 * m + 1
         slot = ws.get((m * stride,), 1)[0]
-        nrm = be.norm(start)
-        be.axpby(1.0 / nrm, start, 0.0, V[0])
+        be.normalize_dev(start, out=V[0])              # no host round trip: the solve has ONE synchronisation, below
         for k in range(m):
             w = V[k + 1]
             matvec(V[k], w)
@@ -79,7 +78,7 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         res = abs(Hm[m, m - 1] * sv[-1])
         be.lincomb(V[:m], sv, out=ritz)
         out = be.empty(*shape)
-        be.axpby(1.0 / be.norm(ritz), ritz, 0.0, out)
+        be.normalize_dev(ritz, out=out)
         return lam, out, fixed_matvecs, res
     for _restart in range(maxiter):
         nrm = be.norm(start)

@@ -286,6 +286,18 @@ class CpuBackend:
         buf[offset + k:offset + 2 * k] = h2
         buf[offset + 2 * k] = n2
 
+    def normalize_dev(self, x, out=None, slot=None, offset=0):
+        y = x if out is None else out
+        n2 = float(self._v(x) @ self._v(x))
+        v = self._v(x) * (1.0 / np.sqrt(n2) if n2 > 0 else 0.0)
+        y.buf[: y.size] = torch.from_numpy(np.ascontiguousarray(v))
+        if slot is not None:
+            slot.buf.numpy()[offset] = n2
+        return y
+
+    def nrm2_dev(self, x, slot, offset=0):
+        slot.buf.numpy()[offset] = float(self._v(x) @ self._v(x))
+
     def lincomb(self, xs, coefs, out=None):
         y = self.empty(xs[0].shape) if out is None else out
         v = sum(float(c) * self._v(x) for c, x in zip(coefs, xs))
