@@ -236,6 +236,14 @@ int mpsk_vlincomb(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const 
  * solve / sweep instead of stalling the stream at every use (normalize! in toolbox.jl:18, fixedpoint.jl:19-30).
  * dev_n2 (optional, device memory, one double) receives |x|^2. */
 int mpsk_vnormalize_dev(mpsk_ctx* ctx, int64_t n, const void* x, void* y, void* dev_n2);
+/* Ritz step of a fixed-budget solve without leaving the device: dev_slot holds, for step k at offset k * stride, the
+ * 2 (k + 1) + 1 scalars of mpsk_vorth_step_dev; dev_coef[0..m) receives the eigenvector of the smallest eigenvalue of
+ * the projected (m <= 32) matrix (positive component on the start vector; zeros beyond an invariant-subspace cut) and
+ * dev_info (optional, 3 doubles) {eigenvalue, residual estimate, effective m}.  mpsk_vlincomb_dev assembles
+ * y = sum_j dev_coefs[j] xs[j] from device-resident coefficients.  (KrylovKit's eigsolve does this step on the host;
+ * fixedpoint.jl:19-30 only uses the vector.) */
+int mpsk_vritz_dev(mpsk_ctx* ctx, int m, int stride, const void* dev_slot, void* dev_coef, void* dev_info);
+int mpsk_vlincomb_dev(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const void* dev_coefs, void* y);
 int mpsk_vnrm2_dev(mpsk_ctx* ctx, int64_t n, const void* x, void* dev_out);
 
 #ifdef __cplusplus

@@ -68,7 +68,7 @@ def updatetol(tol_min, tol_max, factor, it, eps):  # dynamictols.jl:50-53
     return min(max(eps * factor / math.sqrt(it), tol_min), tol_max)
 
 
-def fixedpoint(be, A, x0, alg: Arnoldi, ws=None, first_image=None):
+def fixedpoint(be, A, x0, alg: Arnoldi, ws=None, first_image=None, values=True):
     """fixedpoint(A, x0, :SR, alg)  (fixedpoint.jl:19-30); non-convergence only warns.
     A native complex operator (cplx.HalfEmbeddedOp) given an EMBEDDED start tensor is solved on the half-embedded
     (interleaved complex) vectors: encode once, iterate, decode once."""
@@ -78,7 +78,7 @@ def fixedpoint(be, A, x0, alg: Arnoldi, ws=None, first_image=None):
         fi, first_image = first_image, (None if first_image is None else be.empty(*x0.shape))
     lam, vec, nmv, res = krylov.eigsolve_sr(be, A, x0, tol=alg.tol, krylovdim=alg.krylovdim,
                                             maxiter=alg.maxiter, fixed_matvecs=alg.fixed_matvecs, ws=ws,
-                                            first_image=first_image)
+                                            first_image=first_image, values=values)
     if wrap:
         vec = A.decode(vec)
         if fi is not None:
@@ -205,7 +205,7 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
         # the eigensolver's first matvec is H_AC (AC_old / |AC_old|): exactly the vector calc_galerkin of the old
         # tensor normalises (toolbox.jl:18), so it is captured instead of applying H_AC to AC_old a second time
         g = be.empty(*x0.shape)
-        _, vec = fixedpoint(be, h, x0, eigalg, ws, first_image=g)
+        _, vec = fixedpoint(be, h, x0, eigalg, ws, first_image=g, values=False)   # the sweep only uses the vector
         if enc is not None:
             vec, g = h.decode(vec), h.decode(g)
         if psi.ALs[pos] is None and pos < L - 1:

@@ -503,6 +503,17 @@ class Backend:
         """slot[offset] = |x|^2 on the device, no host sync."""
         check(self.lib.mpsk_vnrm2_dev(self.ctx, x.size, x.ptr, slot.ptr + 8 * offset), "mpsk_vnrm2_dev")
 
+    RITZ_BUF = 40   # doubles: coefficients [0:32], info (lambda, residual estimate, effective m) [32:35]
+
+    def ritz_dev(self, m: int, stride: int, slot: DTensor, buf: DTensor):
+        """Ritz coefficients of a fixed-budget solve on the device (mpsk_vritz_dev): buf[0:m], buf[32:35] = info."""
+        check(self.lib.mpsk_vritz_dev(self.ctx, int(m), int(stride), slot.ptr, buf.ptr, buf.ptr + 8 * 32), "mpsk_vritz_dev")
+
+    def lincomb_dev(self, xs, coef: DTensor, out: DTensor = None):
+        y = self.empty(xs[0].shape) if out is None else out
+        check(self.lib.mpsk_vlincomb_dev(self.ctx, y.size, len(xs), self._ptrs(xs), coef.ptr, y.ptr), "mpsk_vlincomb_dev")
+        return y
+
     def lincomb(self, xs, coefs, out: DTensor = None):
         y = self.empty(xs[0].shape) if out is None else out
         cf = (C.c_double * len(xs))(*[float(c) for c in coefs])

@@ -1365,6 +1365,25 @@ int mpsk_vlincomb(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const do
   return MPSK_OK;
 }
 
+// Ritz coefficients of a fixed-budget solve from the scalars mpsk_vorth_step_dev collected (see ritz_small_kernel)
+int mpsk_vritz_dev(mpsk_ctx* c, int m, int stride, const void* dev_slot, void* dev_coef, void* dev_info) {
+  REQUIRE(c && dev_slot && dev_coef, "NULL argument");
+  REQUIRE(m > 0 && m <= 32 && stride >= 2 * m + 1, "needs 0 < m <= 32 and stride >= 2 m + 1");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(vec_ritz_small((const double*)dev_slot, m, stride, (double*)dev_coef, (double*)dev_info, c->stream));
+  return MPSK_OK;
+}
+
+// y = sum_j dev_coefs[j] xs[j] with the coefficients already on the device
+int mpsk_vlincomb_dev(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const void* dev_coefs, void* y) {
+  REQUIRE(c && xs && y && dev_coefs, "NULL argument");
+  REQUIRE(k > 0 && k <= MAXK && n > 0, "bad k or n");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemsetAsync(y, 0, sizeof(double) * n, c->stream));
+  HIPCHK(vec_multiaxpy((const double* const*)xs, (const double*)dev_coefs, k, 1.0, (double*)y, n, c->stream));
+  return MPSK_OK;
+}
+
 // y = x / |x| without a host synchronisation; |x|^2 is left in dev_n2 (device memory, one double) when given
 int mpsk_vnormalize_dev(mpsk_ctx* c, int64_t n, const void* x, void* y, void* dev_n2) {
   REQUIRE(c && x && y, "NULL argument");

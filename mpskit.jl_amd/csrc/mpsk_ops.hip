@@ -318,6 +318,129 @@ hipError_t vec_scal_rsqrt_dev(const double* d_n2, double* x, int64_t n, hipStrea
   return hipGetLastError();
 }
 
+// ---- Ritz step of a fixed-budget Krylov solve, on the device --------------------------------------------------------
+// slot holds, for step k = 0 .. m-1 at offset k * stride, the 2 (k+1) + 1 scalars mpsk_vorth_step_dev left there:
+// h1[0..k], h2[0..k], |remainder|^2.  One wave builds the projected matrix H (h = h1 + h2, beta = sqrt of the last),
+// cuts it at the first beta <= 1e-13 max|H| (invariant subspace: the later columns were built from a renormalised
+// rounding residual), diagonalises the symmetrised H by cyclic Jacobi and writes the eigenvector of the SMALLEST
+// eigenvalue (sign: positive component on the start vector) to coef[0..m) (zeros beyond the cut) and
+// info = {lambda, |beta_last * s_last|, m_eff}.  The host variant (numpy eigh on the downloaded slot) costs one stream
+// stall and ~150 us of idle GPU per site of a sweep; this one keeps the whole solve asynchronous.
+constexpr int RITZ_MAX = 32;
+__device__ __forceinline__ double ritz_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  return r * (2.0 - x * r);
+}
+__device__ __forceinline__ double ritz_rsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r * (1.5 - 0.5 * x * r * r);
+}
+__global__ __launch_bounds__(64) void ritz_small_kernel(const double* __restrict__ slot, int m, int stride,
+                                                        double* __restrict__ coef, double* __restrict__ info) {
+  __shared__ double A[RITZ_MAX][RITZ_MAX + 1], V[RITZ_MAX][RITZ_MAX + 1], beta[RITZ_MAX];
+  __shared__ int meff_s, rp[RITZ_MAX / 2], rq[RITZ_MAX / 2];
+  __shared__ double rc[RITZ_MAX / 2], rs[RITZ_MAX / 2];
+  const int t = threadIdx.x;
+  for (int e = t; e < RITZ_MAX * RITZ_MAX; e += 64) { A[e / RITZ_MAX][e % RITZ_MAX] = 0.0; V[e / RITZ_MAX][e % RITZ_MAX] = (e / RITZ_MAX == e % RITZ_MAX) ? 1.0 : 0.0; }
+  __syncthreads();
+  if (t < m) {                               // column t of H
+    const int kk = t + 1;
+    const double* blk = slot + (int64_t)t * stride;
+    for (int j = 0; j < kk && j < m; ++j) A[j][t] = blk[j] + blk[kk + j];
+    const double n2 = blk[2 * kk];
+    beta[t] = n2 > 0.0 ? sqrt(n2) : 0.0;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double scale = 1e-300;
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) scale = fmax(scale, fabs(A[i][j]));
+    // (the sub-diagonal entries H[k+1][k] = beta[k] belong to the (m+1) x m matrix; only k + 1 < m ones lie in the square part)
+    for (int k = 0; k + 1 < m; ++k) scale = fmax(scale, beta[k]);
+    int me = m;
+    for (int k = 0; k < m; ++k) if (beta[k] <= 1e-13 * scale) { me = k + 1; break; }
+    meff_s = me;
+  }
+  __syncthreads();
+  const int me = meff_s;
+  // square part of the Arnoldi matrix: upper triangle from the dots, sub-diagonal from the betas; symmetrise
+  if (t == 0) {
+    for (int k = 0; k + 1 < me; ++k) A[k + 1][k] = beta[k];
+    for (int i = 0; i < me; ++i)
+      for (int j = i + 1; j < me; ++j) { const double v = 0.5 * (A[i][j] + A[j][i]); A[i][j] = v; A[j][i] = v; }
+  }
+  __syncthreads();
+  // cyclic Jacobi in the round-robin (tournament) order: ne / 2 disjoint rotations per round, one lane per rotation for
+  // the angles, lanes x pairs for the column / row updates (the serial (p, q) order spent ~0.5 ms in dependent sqrt / div
+  // chains for m = 8 -- longer than the host round trip this kernel replaces)
+  const int ne = me + (me & 1);                         // even player count; index me (if odd) is a bye
+  const int half = ne / 2;
+  for (int sweep = 0; sweep < 24; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    for (int i = 0; i < me; ++i) for (int j = 0; j < me; ++j) { if (i != j) off += A[i][j] * A[i][j]; else dia += A[i][i] * A[i][i]; }
+    if (off <= 1e-30 * dia) break;                       // (uniform: every lane reads the same LDS values)
+    for (int round = 0; round < ne - 1; ++round) {
+      __syncthreads();
+      if (t < half) {                                    // pair t of this round: circle method with player ne - 1 fixed
+        int a = (t == 0) ? ne - 1 : (round + t) % (ne - 1);
+        int b = (round + ne - 1 - t) % (ne - 1);
+        int pp = a < b ? a : b, qq = a < b ? b : a;
+        double c = 1.0, sn = 0.0;
+        if (qq < me) {
+          const double apq = A[pp][qq], app = A[pp][pp], aqq = A[qq][qq];
+          if (apq * apq > 1e-36 * fabs(app * aqq) && fabs(apq) > 1e-300) {
+            // hardware reciprocal / reciprocal-square-root seeds + Newton steps: the IEEE divide / sqrt expansions are
+            // ~40-instruction dependent chains each and five of them sit on the critical path of every round
+            const double theta = (aqq - app) * 0.5 * ritz_rcp(apq);
+            const double h2 = theta * theta + 1.0;
+            const double hyp = h2 * ritz_rsq(h2);                                  // sqrt(theta^2 + 1)
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) * ritz_rcp(fabs(theta) + hyp);
+            c = ritz_rsq(tt * tt + 1.0); sn = tt * c;
+          }
+        } else { qq = pp; }                              // bye: identity on (pp, pp), never applied
+        rp[t] = pp; rq[t] = qq; rc[t] = c; rs[t] = sn;
+      }
+      __syncthreads();
+      for (int e = t; e < half * me; e += 64) {          // columns p, q of A and V (e -> pair, row)
+        const int r = e / me, i = e - r * me, pp = rp[r], qq = rq[r];
+        if (pp == qq) continue;
+        const double c = rc[r], sn = rs[r];
+        const double aip = A[i][pp], aiq = A[i][qq];
+        A[i][pp] = c * aip - sn * aiq; A[i][qq] = sn * aip + c * aiq;
+        const double vip = V[i][pp], viq = V[i][qq];
+        V[i][pp] = c * vip - sn * viq; V[i][qq] = sn * vip + c * viq;
+      }
+      __syncthreads();
+      for (int e = t; e < half * me; e += 64) {          // rows p, q of A
+        const int r = e / me, i = e - r * me, pp = rp[r], qq = rq[r];
+        if (pp == qq) continue;
+        const double c = rc[r], sn = rs[r];
+        const double api = A[pp][i], aqi = A[qq][i];
+        A[pp][i] = c * api - sn * aqi; A[qq][i] = sn * api + c * aqi;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (t == 0) {
+    int best = 0;
+    for (int i = 1; i < me; ++i) if (A[i][i] < A[best][best]) best = i;
+    double nrm = 0.0;
+    for (int i = 0; i < me; ++i) nrm += V[i][best] * V[i][best];
+    double sc = 1.0 / sqrt(nrm);
+    if (V[0][best] < 0.0) sc = -sc;
+    for (int i = 0; i < m; ++i) coef[i] = i < me ? sc * V[i][best] : 0.0;
+    if (info) { info[0] = A[best][best]; info[1] = fabs(beta[me - 1] * sc * V[me - 1][best]); info[2] = (double)me; }
+  }
+}
+
+hipError_t vec_ritz_small(const double* d_slot, int m, int stride, double* d_coef, double* d_info, hipStream_t s) {
+  if (m <= 0 || m > RITZ_MAX) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ritz_small_kernel, dim3(1), dim3(64), 0, s, d_slot, m, stride, d_coef, d_info);
+  return hipGetLastError();
+}
+
 hipError_t vec_scal(double a, double* x, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   int64_t nb = (n + 255) / 256;

@@ -27,13 +27,16 @@ class KrylovWorkspace:
 
 
 def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxiter=100,
-                fixed_matvecs=None, ws: KrylovWorkspace | None = None, first_image: DTensor | None = None):
+                fixed_matvecs=None, ws: KrylovWorkspace | None = None, first_image: DTensor | None = None,
+                values: bool = True):
     """Smallest-real eigenpair of a Hermitian operator: restarted Lanczos/Arnoldi with twice-iterated
     classical Gram-Schmidt and an 'eager' convergence test each step (defaults.jl:33:
     Arnoldi(; tol, maxiter, eager=true)).  matvec(x: DTensor, out: DTensor) -> out.
     first_image: optional buffer that receives A (x0 / |x0|), the very first matvec of the solve, before it is
     orthogonalised -- calc_galerkin of the OLD tensor needs exactly this vector (toolbox.jl:18), so the DMRG sweep
     does not apply the effective Hamiltonian to the same tensor twice.
+    values=False (fixed-budget solves only): the caller needs the vector alone -- the Ritz step then runs on the device
+    as well (mpsk_vritz_dev) and the solve returns (None, vec, n_matvecs, None) without ever stalling the stream.
     Returns (lambda, vec, n_matvecs, residual)."""
     ws = KrylovWorkspace(be) if ws is None else ws
     shape = x0.shape
@@ -58,6 +61,13 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
             if k == 0 and first_image is not None:
                 be.axpby(1.0, w, 0.0, first_image)
             be.orth_step_dev(V[:k + 1], w, slot, k * stride)
+        if not values and m <= 32 and hasattr(be, "ritz_dev"):
+            rb = ws.get((be.RITZ_BUF, 1), 1)[0]
+            be.ritz_dev(m, stride, slot, rb)
+            be.lincomb_dev(V[:m], rb, out=ritz)
+            out = be.empty(*shape)
+            be.normalize_dev(ritz, out=out)
+            return None, out, fixed_matvecs, None
         co = be.download(slot)
         Hm = np.zeros((m + 1, m))
         for k in range(m):

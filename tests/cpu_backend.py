@@ -298,6 +298,33 @@ class CpuBackend:
     def nrm2_dev(self, x, slot, offset=0):
         slot.buf.numpy()[offset] = float(self._v(x) @ self._v(x))
 
+    RITZ_BUF = 40
+
+    def ritz_dev(self, m, stride, slot, buf):
+        co = slot.buf.numpy()
+        Hm = np.zeros((m + 1, m))
+        for k in range(m):
+            kk = k + 1
+            blk = co[k * stride:k * stride + 2 * kk + 1]
+            Hm[:kk, k] = blk[:kk] + blk[kk:2 * kk]
+            Hm[kk, k] = np.sqrt(max(blk[2 * kk], 0.0))
+        scale = max(np.abs(Hm[:m, :m]).max(), 1e-300)
+        me = m
+        for k in range(m):
+            if Hm[k + 1, k] <= 1e-13 * scale:
+                me = k + 1
+                break
+        Hk = Hm[:me, :me]
+        ev, S = np.linalg.eigh((Hk + Hk.T) / 2)
+        sv = S[:, 0] * (1.0 if S[0, 0] >= 0 else -1.0)
+        out = buf.buf.numpy().reshape(-1)
+        out[:m] = 0.0
+        out[:me] = sv
+        out[32:35] = [ev[0], abs(Hm[me, me - 1] * sv[-1]), me]
+
+    def lincomb_dev(self, xs, coef, out=None):
+        return self.lincomb(xs, coef.buf.numpy().reshape(-1)[:len(xs)], out=out)
+
     def lincomb(self, xs, coefs, out=None):
         y = self.empty(xs[0].shape) if out is None else out
         v = sum(float(c) * self._v(x) for c, x in zip(coefs, xs))

@@ -531,3 +531,33 @@ def test_bond_matrix_inverse_on_device(be):
         Cm = (U * np.logspace(0, -grade, D)) @ V.T if grade else rng.standard_normal((D, D))
         inv = be.download(alg._bond_inv(be, be.upload(Cm)))
         assert np.abs(inv @ Cm - np.eye(D)).max() < 1e-9 * np.linalg.cond(Cm)
+
+
+def test_device_ritz_step_matches_host(be):
+    """Fixed-budget eigsolve with the Ritz step on the device (values=False: mpsk_vritz_dev + mpsk_vlincomb_dev, no host
+    synchronisation) against the same solve with the host Ritz step (numpy eigh on the downloaded scalars), including an
+    invariant-subspace cut (operator of rank 3 -> the Krylov space closes after 3-4 steps)."""
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import krylov
+    rng = np.random.default_rng(11)
+    n = 96
+    for rank in (None, 3):
+        M = rng.standard_normal((n, n)); M = M + M.T
+        if rank is not None:
+            U = np.linalg.qr(rng.standard_normal((n, rank)))[0]
+            M = U @ np.diag([-3.0, 1.0, 2.5]) @ U.T
+        Md = be.upload(M)
+
+        def mv(x, out):
+            return be.gemm(Md, x.reshape(n, 1), out=out.reshape(n, 1))
+
+        x0 = be.upload(rng.standard_normal((n, 1, 1)))
+        for m in (1, 2, 5, 8, 20):
+            lam, v1, _, res = krylov.eigsolve_sr(be, mv, x0, fixed_matvecs=m, krylovdim=m)
+            none, v2, _, none2 = krylov.eigsolve_sr(be, mv, x0, fixed_matvecs=m, krylovdim=m, values=False)
+            assert none is None and none2 is None
+            a, b = be.download(v1).ravel(), be.download(v2).ravel()
+            assert abs(np.linalg.norm(b) - 1.0) < 1e-13
+            assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-11, (rank, m)
+            assert b @ be.download(x0).ravel() > 0            # sign convention: positive overlap with the start vector
+            assert abs(b @ M @ b - lam) < 1e-10 * max(1.0, abs(lam))

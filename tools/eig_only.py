@@ -14,11 +14,11 @@ x = r(D, d, D)
 h = mk.MPO_ddAC(be, H[1], GL, GR)
 eig = mk.Arnoldi(fixed_matvecs=8, krylovdim=8); ws = krylov.KrylovWorkspace(be)
 for _ in range(3):
-    alg.fixedpoint(be, h, x, eig, ws)
+    alg.fixedpoint(be, h, x, eig, ws, values=os.environ.get("VALUES", "1") == "1")
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
 for _ in range(n):
-    alg.fixedpoint(be, h, x, eig, ws)
+    alg.fixedpoint(be, h, x, eig, ws, values=os.environ.get("VALUES", "1") == "1")
 torch.cuda.synchronize()
 print(f"{(time.perf_counter() - t0) / n * 1e3:.3f} ms per eigsolve")
