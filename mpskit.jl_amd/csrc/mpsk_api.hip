@@ -1315,12 +1315,7 @@ int mpsk_vorth_step(mpsk_ctx* c, int64_t n, int k, const void* const* xs, void* 
   HIPCHK(hipSetDevice(c->device));
   const double* const* X = (const double* const*)xs;
   double* yy = (double*)y;
-  HIPCHK(vec_multidot(X, k, yy, n, c->d_scal, c->d_partial, c->stream));
-  HIPCHK(vec_multiaxpy(X, c->d_scal, k, -1.0, yy, n, c->stream));
-  HIPCHK(vec_multidot(X, k, yy, n, c->d_scal + k, c->d_partial, c->stream));
-  HIPCHK(vec_multiaxpy(X, c->d_scal + k, k, -1.0, yy, n, c->stream));
-  const double* ys[1] = {yy};
-  HIPCHK(vec_multidot(ys, 1, yy, n, c->d_scal + 2 * k, c->d_partial, c->stream));
+  HIPCHK(vec_cgs2(X, k, yy, n, c->d_scal, c->d_partial, c->stream));
   HIPCHK(vec_scal_rsqrt_dev(c->d_scal + 2 * k, yy, n, c->stream));
   double tmp[MAXK];
   if (int rc = fetch_scalars(c, 2 * k + 1, tmp)) return rc;
@@ -1339,12 +1334,7 @@ int mpsk_vorth_step_dev(mpsk_ctx* c, int64_t n, int k, const void* const* xs, vo
   const double* const* X = (const double* const*)xs;
   double* yy = (double*)y;
   double* out = (double*)dev_out;
-  HIPCHK(vec_multidot(X, k, yy, n, out, c->d_partial, c->stream));
-  HIPCHK(vec_multiaxpy(X, out, k, -1.0, yy, n, c->stream));
-  HIPCHK(vec_multidot(X, k, yy, n, out + k, c->d_partial, c->stream));
-  HIPCHK(vec_multiaxpy(X, out + k, k, -1.0, yy, n, c->stream));
-  const double* ys[1] = {yy};
-  HIPCHK(vec_multidot(ys, 1, yy, n, out + 2 * k, c->d_partial, c->stream));
+  HIPCHK(vec_cgs2(X, k, yy, n, out, c->d_partial, c->stream));
   HIPCHK(vec_scal_rsqrt_dev(out + 2 * k, yy, n, c->stream));
   return MPSK_OK;
 }

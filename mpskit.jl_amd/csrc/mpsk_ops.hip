@@ -260,6 +260,97 @@ hipError_t vec_multidot(const double* const* xs, int k, const double* y, int64_t
   return hipGetLastError();
 }
 
+// ---- fused passes of the twice-iterated classical Gram-Schmidt step -------------------------------------------------
+// y <- y + sign * sum_j coefs[j] xs[j]  AND, in the same pass over memory, either the NVEC dots <xs[j], y_new>
+// (NORM == false: the second-round coefficients) or <y_new, y_new> (NORM == true: the squared norm of the remainder).
+// The unfused sequence multiaxpy -> multidot re-reads y and all of xs for the dots: 4k + 9 vector passes per
+// orthogonalisation step against 3k + 8 with these kernels (the step is HBM-bound: ~6 TB/s in both forms).
+// Same grid and per-thread element order as multidot_kernel, so the sums are bit-identical to the unfused ones.
+template <int NVEC, bool NORM>
+__global__ __launch_bounds__(256) void multiaxpy_dot_kernel(PtrPack xs, const double* __restrict__ coefs, double sign,
+                                                            double* __restrict__ y, int64_t n, double* __restrict__ partial) {
+  constexpr int NA = NORM ? 1 : NVEC;
+  __shared__ double sh[4 * NA];
+  double c[NVEC], acc[NA];
+#pragma unroll
+  for (int j = 0; j < NVEC; ++j) c[j] = sign * coefs[j];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) acc[j] = 0.0;
+  const int64_t n2 = n >> 1;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) {
+    d2 yv = *reinterpret_cast<const d2*>(y + 2 * e);
+    d2 xv[NVEC];
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+      xv[j] = *reinterpret_cast<const d2*>(xs.p[j] + 2 * e);
+      yv.x += c[j] * xv[j].x;
+      yv.y += c[j] * xv[j].y;
+    }
+    *reinterpret_cast<d2*>(y + 2 * e) = yv;
+    if (NORM) acc[0] += yv.x * yv.x + yv.y * yv.y;
+    else {
+#pragma unroll
+      for (int j = 0; j < NVEC; ++j) acc[NORM ? 0 : j] += xv[j].x * yv.x + xv[j].y * yv.y;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double v = y[n - 1];
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) v += c[j] * xs.p[j][n - 1];
+    y[n - 1] = v;
+    if (NORM) acc[0] += v * v;
+    else {
+#pragma unroll
+      for (int j = 0; j < NVEC; ++j) acc[NORM ? 0 : j] += xs.p[j][n - 1] * v;
+    }
+  }
+  block_sum<NA>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) partial[(int64_t)j * DOT_BLOCKS + blockIdx.x] = acc[j];
+  }
+}
+
+template <bool NORM>
+static void launch_axpy_dot(int nv, int nb, const PtrPack& pk, const double* cf, double sign, double* y, int64_t n,
+                            double* d_partial, hipStream_t s) {
+  switch (nv) {
+    case 1: hipLaunchKernelGGL((multiaxpy_dot_kernel<1, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+    case 2: hipLaunchKernelGGL((multiaxpy_dot_kernel<2, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+    case 3: hipLaunchKernelGGL((multiaxpy_dot_kernel<3, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+    case 4: hipLaunchKernelGGL((multiaxpy_dot_kernel<4, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+    case 5: hipLaunchKernelGGL((multiaxpy_dot_kernel<5, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+    case 6: hipLaunchKernelGGL((multiaxpy_dot_kernel<6, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+    case 7: hipLaunchKernelGGL((multiaxpy_dot_kernel<7, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+    default: hipLaunchKernelGGL((multiaxpy_dot_kernel<8, NORM>), dim3(nb), dim3(256), 0, s, pk, cf, sign, y, n, d_partial); break;
+  }
+}
+
+// One CGS2 step of y against xs[0..k) with the remainder's squared norm, d_out = {h1[k], h2[k], |y_final|^2}:
+//   h1 = X^T y ; y -= X h1 (+ h2 = X^T y in the same pass) ; y -= X h2 (+ |y|^2 in the same pass).
+// k <= MD vectors go through the fused kernels; longer bases fall back to the separate passes (a chunked axpy cannot
+// carry dots of the FINAL y).  y is left un-normalised.
+hipError_t vec_cgs2(const double* const* xs, int k, double* y, int64_t n, double* d_out, double* d_partial, hipStream_t s) {
+  if (n <= 0 || k <= 0) return hipErrorInvalidValue;
+  hipError_t e = vec_multidot(xs, k, y, n, d_out, d_partial, s);
+  if (e != hipSuccess) return e;
+  if (k > MD) {
+    if ((e = vec_multiaxpy(xs, d_out, k, -1.0, y, n, s)) != hipSuccess) return e;
+    if ((e = vec_multidot(xs, k, y, n, d_out + k, d_partial, s)) != hipSuccess) return e;
+    if ((e = vec_multiaxpy(xs, d_out + k, k, -1.0, y, n, s)) != hipSuccess) return e;
+    const double* ys[1] = {y};
+    return vec_multidot(ys, 1, y, n, d_out + 2 * k, d_partial, s);
+  }
+  const int nb = dot_grid(n);
+  PtrPack pk;
+  for (int j = 0; j < MD; ++j) pk.p[j] = xs[j < k ? j : 0];
+  launch_axpy_dot<false>(k, nb, pk, d_out, -1.0, y, n, d_partial, s);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(k), dim3(256), 0, s, d_partial, nb, d_out + k);
+  launch_axpy_dot<true>(k, nb, pk, d_out + k, -1.0, y, n, d_partial, s);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, d_partial, nb, d_out + 2 * k);
+  return hipGetLastError();
+}
+
 // y = a*x + b*y   (b == 0: y is not read, so it may hold NaN / be uninitialised)
 __global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __restrict__ x, double b,
                                                     double* __restrict__ y, int64_t n) {
