@@ -133,6 +133,54 @@ __global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, do
   const int ntrail = (k == 0) ? 1 : nt * (nt + 1) / 2;
   const int b = blockIdx.x;
   cq_d4 acc[2][2];
+  if (k >= 2 && (k & 1) == 0 && b == ntrail + nt) {
+    // ---- first level of the inverse, off the critical path: the pair of diagonal blocks (a, a+1) = (k-2, k-1) is
+    // complete (R_{a,a+1} from the panel tiles and R_{a+1,a+1}^-1 from the diagonal workgroup of launch k-1), so
+    //   Rinv_{a,a+1} = - Rinv_aa R_{a,a+1} Rinv_{a+1,a+1}
+    // is formed here instead of by the two batched GEMM launches of the b = 64 doubling level after the factorisation.
+    const int a = k - 2;
+    cq_d2 t0[8], t1[8], t2[8];
+    cq_fetch_tile(t0, Rinv + (int64_t)a * CB * (npad + 1), npad, tid);
+    cq_fetch_tile(t1, R + (int64_t)a * CB + (int64_t)(a + 1) * CB * npad, npad, tid);
+    cq_fetch_tile(t2, Rinv + (int64_t)(a + 1) * CB * (npad + 1), npad, tid);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {          // sM <- Rinv_aa^T  (cq_prod contracts the ROW index of both tiles)
+      const int v = tid + 256 * q, r2 = (v & 31) * 2, c = v >> 5;
+      sM[r2 * CQ_SL + c] = t0[q].x;
+      sM[(r2 + 1) * CQ_SL + c] = t0[q].y;
+    }
+    cq_put_tile(sJ, t1, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0};
+    cq_prod(acc, sM, sJ, 1.0, wr, wc, fr, fq);               // P = Rinv_aa R_{a,a+1}
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)                       // sI <- P^T
+          sI[(32 * wr + 16 * ti + fq + 4 * rg) * CQ_SL + 32 * wc + 16 * tj + fr] = acc[ti][tj][rg];
+    cq_put_tile(sJ, t2, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0};
+    cq_prod(acc, sI, sJ, -1.0, wr, wc, fr, fq);              // - P Rinv_{a+1,a+1}
+    double* Xb = Rinv + (int64_t)a * CB + (int64_t)(a + 1) * CB * npad;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          Xb[(32 * wr + 16 * ti + fq + 4 * rg) + (int64_t)(32 * wc + 16 * tj + fr) * npad] = acc[ti][tj][rg];
+    return;
+  }
   if (b >= ntrail) {                       // ---- panel tile: R_{kk, j} = Rinv_kk^T G_{kk, j}
     const int j = k + (b - ntrail);
     cq_d2 t0[8], t1[8];
@@ -301,14 +349,14 @@ __global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, do
   if (wave == 0 && lane == 0 && bad) atomicOr(flag, 1);
 }
 
-// zero everything outside the block upper triangle of R (garbage of the trailing updates) and
-// everything outside the diagonal blocks of Rinv
+// zero everything outside the block upper triangle of R (garbage of the trailing updates) and everything outside the
+// 128 x 128 diagonal pair blocks' upper block triangle of Rinv (diagonal blocks + the pair inverses of the step launches)
 __global__ __launch_bounds__(256) void cq_cleanup_kernel(double* __restrict__ R, double* __restrict__ Rinv, int npad) {
   const int64_t total = (int64_t)npad * npad;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     int r = (int)(e % npad), c = (int)(e / npad);
     if (r / CB > c / CB) R[e] = 0.0;
-    if (r / CB != c / CB) Rinv[e] = 0.0;
+    if (r / CB != c / CB && !(r / (2 * CB) == c / (2 * CB) && r / CB < c / CB)) Rinv[e] = 0.0;   // keep the pair inverses
   }
 }
 
@@ -360,17 +408,18 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
   const int nb = npad / CB;
   static std::atomic<uint64_t> step_attr{0};
   if ((e = ensure_dyn_smem(step_attr, reinterpret_cast<const void*>(cq_step_kernel), CQ_STEP_LDS)) != hipSuccess) return e;
-  for (int k = 0; k < nb; ++k) {            // one fused launch per block column (see cq_step_kernel)
-    const int nt = nb - k;
-    const int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt;
-    hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag);
+  for (int k = 0; k <= nb; ++k) {           // one fused launch per block column (see cq_step_kernel); even launches
+    const int nt = nb - k;                  // k >= 2 carry one more workgroup (pair inverse), k == nb is that one alone
+    const int pairwg = (k >= 2 && (k & 1) == 0) ? 1 : 0;
+    const int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt + pairwg;
+    if (nwg > 0) hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag);
   }
   hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
   // R^{-1} by recursive doubling: inv([R11 R12; 0 R22]) = [i11, -i11 R12 i22; 0, i22]
   // (computing the block columns of R^-1 as extra tiles of the step launches -- X_ic = -(sum_l X_il R_lc) X_cc -- was
   //  measured and rejected: the serial l-loop of a tile, ~2 us per term, is longer than a step from column 12 on and puts
   //  the inverse ON the critical path: 1.95 instead of 1.80 ms at 2048 x 1024, 59 instead of 29 ms at 4096^2)
-  for (int b = CB; b < npad; b <<= 1) {
+  for (int b = 2 * CB; b < npad; b <<= 1) {      // (the b = 64 level comes out of the step launches)
     const int pairs = npad / (2 * b);
     const int64_t bs = (int64_t)2 * b * (npad + 1);
     const int64_t off12 = (int64_t)b * npad;                 // (0, b) block of a pair
