@@ -60,3 +60,40 @@ def test_libmpsk_comm_world1(be):
         assert abs(e1 - e2) <= 1e-10 * abs(e1) and comm.n_allgather > 10
     finally:
         comm.close()
+
+
+def test_torch_rccl_world1_sharded_sweep(be):
+    """dist.Comm over torch.distributed's RCCL backend at world size 1 (force_collective: every all-gather / all-reduce
+    of the sharded sweep is really issued): the collectives are ordered against the ctx stream only through stream
+    semantics -- the sweep has no host synchronisation left that could hide a missing dependency -- so the sharded sweep
+    must reproduce the unsharded one."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import dist as md, algorithms as alg, krylov
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = False
+    if not dist.is_initialized():
+        port = 29900 + os.getpid() % 90
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        comm = md.Comm(1, 0, force_collective=True)
+        H = mk.heisenberg_XXX(0.5, be=be)
+        psi = mk.FiniteMPS.random(14, 2, 128, np.random.default_rng(5), be=be)
+        ps = psi.copy()
+        eig = mk.Arnoldi(fixed_matvecs=6, krylovdim=6)
+        eu, es = mk.FinEnv(psi, H), md.ShardedFinEnv(ps, H, comm, min_block=32, force=True)
+        for _ in range(2):
+            e_u = alg.dmrg_sweep(psi, H, eu, eig, krylov.KrylovWorkspace(be))
+            e_s = alg.dmrg_sweep(ps, H, es, eig, krylov.KrylovWorkspace(be))
+        e1 = float(np.sum(mk.expectation_value(psi, H, eu)))
+        e2 = float(np.sum(mk.expectation_value(ps, H, es)))
+        assert abs(e1 - e2) <= 1e-10 * abs(e1), (e1, e2)
+        assert np.abs(np.array(e_u) - np.array(e_s)).max() <= 1e-8
+        assert comm.n_allgather > 50 and comm.n_allreduce > 10
+    finally:
+        if created:
+            dist.destroy_process_group()
