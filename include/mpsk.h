@@ -177,6 +177,15 @@ int mpsk_qrlq_pair(mpsk_ctx* ctx, int m, int n, const void* A1, int lda1, void* 
                    const void* A2, int lda2, void* L2, int ldl2, void* Q2, int ldq2);
 /* A (m x n, m <= n) = L (m x m lower) * Q (m x n), diag(L) > 0 */
 int mpsk_lqpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq);
+/* Deferred completion of a gauge step.  After mpsk_ctx_qr_defer the NEXT mpsk_qrpos2 / mpsk_lqpos call on the ctx that
+ * takes the CholeskyQR3 path returns as soon as its launches are enqueued: Q / R of mpsk_qrpos2 are speculative, L / Q of
+ * mpsk_lqpos not yet written, until mpsk_qr_commit has read the device's success flag (and run the repeated third pass /
+ * the fallbacks where it asks for them).  *redone: bit 0 / bit 1 = the first / second factorization of the pair was
+ * corrected after its enqueue -- whatever was computed from the speculative factor has to be recomputed.  Between the
+ * two calls only entry points that do not use the ctx workspace are accepted (mpsk_gemm, mpsk_v*): the DMRG sweep
+ * enqueues the galerkin evaluation of the site there (toolbox.jl:17-22), so the stream has work while the host waits. */
+int mpsk_ctx_qr_defer(mpsk_ctx* ctx);
+int mpsk_qr_commit(mpsk_ctx* ctx, int* redone);
 /* thin SVD of theta (m x n): theta = U diag(S) Vh, S descending.  U: m x kmax, S: kmax, Vh: kmax x n
  * buffers with kmax = min(m, n).  Truncation (TensorKit truncdim & truncerr, dmrg.jl:75,96):
  * keep at most max_keep (<= 0: no limit) values and drop the tail while ||S_dropped||_2 <= trunc_err -- an ABSOLUTE

@@ -95,6 +95,8 @@ SIGNATURES = {
     "mpsk_vlincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, c_double_p, C.c_void_p],
     "mpsk_vnormalize_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vnrm2_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "mpsk_ctx_qr_defer": [C.c_void_p],
+    "mpsk_qr_commit": [C.c_void_p, C.POINTER(C.c_int)],
     "mpsk_vritz_dev": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vlincomb_dev": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, C.c_void_p],
 }

@@ -208,17 +208,32 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
         _, vec = fixedpoint(be, h, x0, eigalg, ws, first_image=g, values=False)   # the sweep only uses the vector
         if enc is not None:
             vec, g = h.decode(vec), h.decode(g)
+        # Deferred gauge step (mpsk_ctx_qr_defer / mpsk_qr_commit) on left-moving visits: the LQ factorization the NEXT
+        # visit needs is enqueued first, the galerkin evaluation of this visit (which does not depend on it) behind it,
+        # and only then does the host wait for the factorization's success flag -- the stream has ~0.2 ms of work while
+        # it does (the flag read-back used to leave the GPU idle for ~40 us per visit).  Same tensors, same operations.
+        qdef = defer and hasattr(be, "qr_defer") and not psi.cplx
         if psi.ALs[pos] is None and pos < L - 1:
             # right-moving visit: leftorth(old AC) (galerkin projector) and leftorth(new AC) (next AL)
             # are both due -> issue them together; same state as the lazy views would produce
+            # (not deferred: the galerkin evaluation needs al_old itself, and speculating on it does not pay -- measured
+            #  on the benchmark sweep, a third of the old-AC factorizations repeat their last pass (orthogonality of the
+            #  first-order pass > 1e-7 on these ill-conditioned tensors), and every repeat costs a second projection)
             al_old = psi.set_AC_with_leftorth(pos, vec)
+            e = _galerkin(be, h, ac_old, al_old, g, gslot, iv)
         else:
             # left-moving visit (and the turning point pos = L-1, where the next step is a rightorth): the galerkin
             # projector is leftorth(old AC) (cached AL[pos] if the state holds it), the new AC is stored as is
-            # and gauged lazily when the next site asks for AR[pos] (orthoview.jl:27-31, 49-54)
+            # and gauged when the next site asks for AR[pos] (orthoview.jl:27-31, 49-54) -- here: right away, so
+            # that the galerkin evaluation runs behind it
             al_old = psi.AL(pos)
             psi.set_AC(pos, vec)
-        e = _galerkin(be, h, ac_old, al_old, g, gslot, iv)
+            if qdef and pos > 0:
+                be.qr_defer()
+                psi.AR(pos)
+            e = _galerkin(be, h, ac_old, al_old, g, gslot, iv)
+            if qdef:
+                be.qr_commit()
         if not defer:
             eps_s[pos] = max(eps_s[pos], e)
     if defer:

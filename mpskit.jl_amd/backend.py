@@ -383,6 +383,15 @@ class Backend:
               "mpsk_qrpos2")
         return Q1, R1, Q2, R2
 
+    def qr_defer(self):
+        """the next qrpos2 / lqpos returns once enqueued; finish it with qr_commit (include/mpsk.h)."""
+        check(self.lib.mpsk_ctx_qr_defer(self.ctx), "mpsk_ctx_qr_defer")
+
+    def qr_commit(self) -> int:
+        r = C.c_int(0)
+        check(self.lib.mpsk_qr_commit(self.ctx, C.byref(r)), "mpsk_qr_commit")
+        return r.value
+
     def qrlq_pair(self, A1: DTensor, A2: DTensor):
         """QRpos of A1 (m x n) and LQpos of A2 (n x m) in flight together -> (Q1, R1, L2, Q2)."""
         m, n = A1.shape

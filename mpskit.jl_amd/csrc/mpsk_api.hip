@@ -76,6 +76,17 @@ struct mpsk_ctx {
   void* ws3 = nullptr;          // transposed operands of mpsk_qrlq_pair
   size_t ws3_bytes = 0;
   int* h_flags = nullptr;       // pinned [2]
+  // deferred completion of a CholeskyQR gauge step (mpsk_ctx_qr_defer / mpsk_qr_commit): the launches are enqueued, the
+  // success flag is read (and a fallback run) only at commit -- the caller fills the gap with work that does not need c->ws
+  struct PendingQR {
+    int active = 0;               // 0 none, 1 qrpos2, 2 lqpos
+    int m = 0, n = 0;
+    const void *A1 = nullptr, *A2 = nullptr; void *Q1 = nullptr, *R1 = nullptr, *Q2 = nullptr, *R2 = nullptr;
+    int lda1 = 0, ldq1 = 0, ldr1 = 0, lda2 = 0, ldq2 = 0, ldr2 = 0;
+    double *At = nullptr, *Qt = nullptr, *Rt = nullptr, *ws = nullptr;   // lqpos: transposed problem in c->ws
+    void *L = nullptr, *Qo = nullptr; int ldl = 0, ldqo = 0;
+  } pend;
+  bool defer_next = false;
   std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
   std::vector<PoolBuf> pool;    // device buffers of prepared operators (mpsk_hac), reused across site visits
 };
@@ -374,6 +385,7 @@ int mpsk_mposlice_dims(const mpsk_mposlice* s, int* Wl, int* Wr, int* d) {
 // helpers
 // --------------------------------------------------------------------------------------------
 static int ensure_ws(mpsk_ctx* c, size_t bytes) {
+  if (c->pend.active) return fail(MPSK_ERR_INVALID, "a deferred factorization still owns the workspace: call mpsk_qr_commit first");
   if (bytes <= c->ws_bytes) return MPSK_OK;
   return mpsk_ctx_workspace_reserve(c, bytes + bytes / 4);
 }
@@ -993,8 +1005,70 @@ int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int l
   REQUIRE(m >= n && n > 0, "needs m >= n > 0");
   REQUIRE(lda >= m && ldq >= m && ldr >= n, "leading dimension too small");
   HIPCHK(hipSetDevice(c->device));
+  c->defer_next = false;                       // (single factorizations complete at once)
   if (int rc = ensure_ws(c, sizeof(double) * qr_ws_doubles(m, n))) return rc;
   return qrpos_dispatch(c, m, n, (const double*)A, lda, (double*)Q, ldq, (double*)R, ldr, (double*)c->ws);
+}
+
+// completion of ONE CholeskyQR3 factorization whose launches are already on `s`: wait, read the device flag, repeat the
+// third pass / run the fallbacks (robust CholeskyQR, Householder) if it asks for them.  *redone: the outputs changed
+// after the enqueue (anything a caller computed from them speculatively has to be recomputed).
+static int qr_complete_one(mpsk_ctx* c, int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr,
+                           double* ws, int* d_flag, int* h_flag, hipStream_t s, bool* redone) {
+  HIPCHK(hipStreamSynchronize(s));
+  const int pre = *h_flag;
+  hipError_t e = cholqr3_finalize(m, n, Q, ldq, R, ldr, ws, d_flag, h_flag, s);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 finalize: ") + hipGetErrorString(e));
+  if (redone) *redone = (pre != 0);
+  if (*h_flag == 0) { c->n_qr_chol++; return MPSK_OK; }
+  if (c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
+  c->n_qr_fallback++;
+  int flag = 0;
+  e = cholqr_robust(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr_robust: ") + hipGetErrorString(e));
+  if (flag == 0) { c->n_qr_robust++; return MPSK_OK; }
+  c->n_qr_house++;
+  std::string err;
+  e = qrpos(m, n, A, lda, Q, ldq, R, ldr, ws, c->stream, &err);
+  if (e != hipSuccess) return fail(err.empty() ? MPSK_ERR_HIP : MPSK_ERR_INVALID, "qrpos: " + (err.empty() ? std::string(hipGetErrorString(e)) : err));
+  return MPSK_OK;
+}
+
+static int qrpos2_complete(mpsk_ctx* c, int* redone) {
+  mpsk_ctx::PendingQR P = c->pend;
+  c->pend.active = 0;
+  bool r1 = false, r2 = false;
+  // (the first factorization's fallbacks use c->ws / the main stream: both free once its own stream is drained; the
+  //  second one's are run after the join, on the main stream as well)
+  if (int rc = qr_complete_one(c, P.m, P.n, (const double*)P.A1, P.lda1, (double*)P.Q1, P.ldq1, (double*)P.R1, P.ldr1,
+                               (double*)c->ws, c->d_flag, &c->h_flags[0], c->stream, &r1)) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream2));
+  const int pre2 = c->h_flags[1];
+  hipError_t e = cholqr3_finalize(P.m, P.n, (double*)P.Q2, P.ldq2, (double*)P.R2, P.ldr2, (double*)c->ws2, c->d_flag + 8,
+                                  &c->h_flags[1], c->stream2);
+  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 finalize (2): ") + hipGetErrorString(e));
+  // join: later work on the main stream is ordered after stream2 (already drained by finalize)
+  HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  r2 = (pre2 != 0);
+  if (c->h_flags[1] == 0) c->n_qr_chol++;
+  else {
+    if (c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
+    c->n_qr_fallback++;
+    int flag = 0;
+    hipError_t e2 = cholqr_robust(P.m, P.n, (const double*)P.A2, P.lda2, (double*)P.Q2, P.ldq2, (double*)P.R2, P.ldr2,
+                                  (double*)c->ws, c->d_flag, &flag, c->stream);
+    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "cholqr_robust (pair) failed");
+    if (flag == 0) c->n_qr_robust++;
+    else {
+      c->n_qr_house++;
+      std::string err;
+      e2 = qrpos(P.m, P.n, (const double*)P.A2, P.lda2, (double*)P.Q2, P.ldq2, (double*)P.R2, P.ldr2, (double*)c->ws, c->stream, &err);
+      if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (pair) failed");
+    }
+  }
+  if (redone) *redone = (r1 ? 1 : 0) | (r2 ? 2 : 0);
+  return MPSK_OK;
 }
 
 // Two independent QRpos factorizations of equal shape, in flight together on two streams (the
@@ -1007,6 +1081,8 @@ int mpsk_qrpos2(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1, i
   REQUIRE(m >= n && n > 0, "needs m >= n > 0");
   REQUIRE(lda1 >= m && ldq1 >= m && ldr1 >= n && lda2 >= m && ldq2 >= m && ldr2 >= n, "leading dimension too small");
   HIPCHK(hipSetDevice(c->device));
+  const bool defer = c->defer_next;
+  c->defer_next = false;
   const size_t wsd = qr_ws_doubles(m, n);
   if (int rc = ensure_ws(c, sizeof(double) * wsd)) return rc;
   if (c->qr_mode == 1 || n <= 64) {
@@ -1030,32 +1106,47 @@ int mpsk_qrpos2(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1, i
   e = cholqr3_enqueue(m, n, (const double*)A2, lda2, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws2,
                       c->d_flag + 8, &c->h_flags[1], c->stream2);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 (2): ") + hipGetErrorString(e));
-  e = cholqr3_finalize(m, n, (double*)Q1, ldq1, (double*)R1, ldr1, (double*)c->ws, c->d_flag, &c->h_flags[0], c->stream);
-  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 finalize (1): ") + hipGetErrorString(e));
-  e = cholqr3_finalize(m, n, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws2, c->d_flag + 8, &c->h_flags[1], c->stream2);
-  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 finalize (2): ") + hipGetErrorString(e));
-  // join: later work on the main stream is ordered after stream2 (already drained by finalize)
-  HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  const int f1 = c->h_flags[0], f2 = c->h_flags[1];
-  if (f1 == 0) c->n_qr_chol++;
-  if (f2 == 0) c->n_qr_chol++;
-  if ((f1 != 0 || f2 != 0) && c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
-  std::string err;
-  const void* As[2] = {A1, A2}; void* Qs[2] = {Q1, Q2}; void* Rs[2] = {R1, R2};
-  const int ldas[2] = {lda1, lda2}, ldqs[2] = {ldq1, ldq2}, ldrs[2] = {ldr1, ldr2}, fl[2] = {f1, f2};
-  for (int t = 0; t < 2; ++t) {
-    if (fl[t] == 0) continue;
-    c->n_qr_fallback++;
-    int flag = 0;
-    hipError_t e2 = cholqr_robust(m, n, (const double*)As[t], ldas[t], (double*)Qs[t], ldqs[t], (double*)Rs[t], ldrs[t],
-                                  (double*)c->ws, c->d_flag, &flag, c->stream);
-    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "cholqr_robust (pair) failed");
-    if (flag == 0) { c->n_qr_robust++; continue; }
-    c->n_qr_house++;
-    e2 = qrpos(m, n, (const double*)As[t], ldas[t], (double*)Qs[t], ldqs[t], (double*)Rs[t], ldrs[t], (double*)c->ws, c->stream, &err);
-    if (e2 != hipSuccess) return fail(MPSK_ERR_HIP, "qrpos fallback (pair) failed");
-  }
+  mpsk_ctx::PendingQR& P = c->pend;
+  P.active = 1; P.m = m; P.n = n;
+  P.A1 = A1; P.lda1 = lda1; P.Q1 = Q1; P.ldq1 = ldq1; P.R1 = R1; P.ldr1 = ldr1;
+  P.A2 = A2; P.lda2 = lda2; P.Q2 = Q2; P.ldq2 = ldq2; P.R2 = R2; P.ldr2 = ldr2;
+  if (defer) return MPSK_OK;                   // outputs are speculative until mpsk_qr_commit
+  return qrpos2_complete(c, nullptr);
+}
+
+static int lqpos_complete(mpsk_ctx* c, int* redone) {
+  mpsk_ctx::PendingQR P = c->pend;
+  c->pend.active = 0;
+  bool r1 = false;
+  // the transposed problem: At (n x m) = Qt Rt; fallbacks write the same Qt / Rt
+  if (int rc = qr_complete_one(c, P.n, P.m, P.At, P.n, P.Qt, P.n, P.Rt, P.m, P.ws, c->d_flag, &c->h_flags[0], c->stream, &r1)) return rc;
+  HIPCHK(transpose(P.Qt, P.n, P.n, P.m, (double*)P.Qo, P.ldqo, c->stream));
+  HIPCHK(transpose(P.Rt, P.m, P.m, P.m, (double*)P.L, P.ldl, c->stream));
+  if (redone) *redone = 0;                     // L / Q are only written here: nothing speculative to redo
+  (void)r1;
+  return MPSK_OK;
+}
+
+// The NEXT mpsk_qrpos2 / mpsk_lqpos call on this ctx that takes the CholeskyQR3 path returns as soon as its launches
+// are enqueued; its outputs are speculative (qrpos2) / not yet written (lqpos) until mpsk_qr_commit.  Between the two
+// calls only entry points that do not use the ctx workspace are accepted (mpsk_gemm, the mpsk_v* family): the sweep
+// enqueues the galerkin evaluation there, so the GPU is not idle while the host waits for the success flag.
+int mpsk_ctx_qr_defer(mpsk_ctx* c) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE(!c->pend.active, "a deferred factorization is already pending");
+  c->defer_next = true;
+  return MPSK_OK;
+}
+
+// *redone: bit 0 / bit 1 = the first / second factorization of a deferred mpsk_qrpos2 was corrected after its enqueue
+// (third pass repeated or a fallback ran): results computed from the speculative Q / R must be recomputed.
+int mpsk_qr_commit(mpsk_ctx* c, int* redone) {
+  REQUIRE(c, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  c->defer_next = false;
+  if (redone) *redone = 0;
+  if (c->pend.active == 1) return qrpos2_complete(c, redone);
+  if (c->pend.active == 2) return lqpos_complete(c, redone);
   return MPSK_OK;
 }
 
@@ -1093,6 +1184,8 @@ int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int l
   REQUIRE(m <= n && m > 0, "needs 0 < m <= n");
   REQUIRE(lda >= m && ldq >= m && ldl >= m, "leading dimension too small");
   HIPCHK(hipSetDevice(c->device));
+  const bool defer = c->defer_next;
+  c->defer_next = false;
   const size_t qws = qr_ws_doubles(n, m);
   const size_t extra = (size_t)2 * n * m + (size_t)m * m;
   if (int rc = ensure_ws(c, sizeof(double) * (qws + extra))) return rc;
@@ -1101,6 +1194,15 @@ int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int l
   double* Rt = Qt + (size_t)n * m;        // m x m
   double* ws2 = Rt + (size_t)m * m;
   HIPCHK(transpose((const double*)A, lda, m, n, At, n, c->stream));
+  if (defer && c->qr_mode != 1 && m > 64) {
+    c->h_flags[0] = 0;
+    hipError_t e = cholqr3_enqueue(n, m, At, n, Qt, n, Rt, m, ws2, c->d_flag, &c->h_flags[0], c->stream);
+    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3: ") + hipGetErrorString(e));
+    mpsk_ctx::PendingQR& P = c->pend;
+    P.active = 2; P.m = m; P.n = n; P.At = At; P.Qt = Qt; P.Rt = Rt; P.ws = ws2;
+    P.L = L; P.ldl = ldl; P.Qo = Q; P.ldqo = ldq;
+    return MPSK_OK;
+  }
   if (int rc = qrpos_dispatch(c, n, m, At, n, Qt, n, Rt, m, ws2)) return rc;
   HIPCHK(transpose(Qt, n, n, m, (double*)Q, ldq, c->stream));
   HIPCHK(transpose(Rt, m, m, m, (double*)L, ldl, c->stream));

@@ -298,6 +298,12 @@ class CpuBackend:
     def nrm2_dev(self, x, slot, offset=0):
         slot.buf.numpy()[offset] = float(self._v(x) @ self._v(x))
 
+    def qr_defer(self):
+        pass
+
+    def qr_commit(self):
+        return 0
+
     RITZ_BUF = 40
 
     def ritz_dev(self, m, stride, slot, buf):
