@@ -1299,7 +1299,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   }
   std::string err;
   hipError_t e = tsvd(nn, nn, Rb, nn, Y, nn, (double*)S, nullptr, 1, max_keep, trunc_err, kept, disc_norm, c->ws, c->stream,
-                      &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, nullptr, /*vfree=*/1);
+                      &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->stream2, /*vfree=*/1);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
   const int k = *kept;
   REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");

@@ -382,7 +382,7 @@ static SvdPlan svd_plan(int m, int n) {
   p.Q = q;
   size_t d = (size_t)2 * p.mm * p.npad + (size_t)2 * p.nn * p.npad + (size_t)p.P * p.Q * J2 * J2 +
              (size_t)2 * p.P * J2 * J2 + (size_t)p.npad * 2 + 64;
-  size_t tabs = (size_t)8 * (2 * p.P) * sizeof(int64_t) + (size_t)p.P * p.Q * 2 * sizeof(int64_t) + 256;
+  size_t tabs = (size_t)16 * (2 * p.P) * sizeof(int64_t) + (size_t)p.P * p.Q * 2 * sizeof(int64_t) + 256;
   p.bytes = d * sizeof(double) + tabs + (size_t)p.npad * sizeof(int);
   return p;
 }
@@ -405,6 +405,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   // converged G = R^T W, i.e. the RIGHT singular vectors of R (and of the matrix R came from).  The caller rebuilds the
   // other factor from the original matrix (mpsk_tsplit).
   SvdPlan pl = svd_plan(m, n);
+  hipStream_t s_phase = s2;                // second stream of the phased V-free schedule (below)
   if (vfree) {
     if (m != n) return hipErrorInvalidValue;
     pl.transposed = 1;
@@ -434,7 +435,8 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   int64_t* t_updB = t_updA_V + 2 * P;
   int64_t* t_updC_G = t_updB + 2 * P;
   int64_t* t_updC_V = t_updC_G + 2 * P;
-  int* d_perm = (int*)(t_updC_V + 2 * P);
+  int64_t* t_phase = t_updC_V + 2 * P;     // 5 destination tables x 2P entries (phased schedule)
+  int* d_perm = (int*)(t_phase + 10 * P);
 
   // round-robin tournament on 2P blocks: slot 2p = top[p], 2p+1 = bottom[p]
   auto dest_slot = [&](int p, int half) -> int {
@@ -448,7 +450,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     return 2 * (p - 1) + 1;                // bottom[p] -> bottom[p-1]
   };
   const int kq = mm / Q;                   // rows per K-split (Q divides mm by construction)
-  std::vector<int64_t> h((size_t)2 * P * Q + 10 * P);
+  std::vector<int64_t> h((size_t)2 * P * Q + 20 * P);
   int64_t* hgA = h.data(); int64_t* hgC = hgA + (size_t)P * Q;
   int64_t* huAG = hgC + (size_t)P * Q; int64_t* huAV = huAG + 2 * P; int64_t* huB = huAV + 2 * P;
   int64_t* huCG = huB + 2 * P; int64_t* huCV = huCG + 2 * P;
@@ -465,6 +467,54 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     huCG[P + p] = (int64_t)dest_slot(p, 1) * JB * mm;
     huCV[p] = (int64_t)dest_slot(p, 0) * JB * nn;
     huCV[P + p] = (int64_t)dest_slot(p, 1) * JB * nn;
+  }
+  // ---- phased schedule (V-free mode, mpsk_tsplit) --------------------------------------------------------------------
+  // The rotation kernel is latency-bound (one workgroup per pair, ~100 us) and leaves most of the chip idle; cutting the
+  // plain round-robin into stream groups needs two cross-queue events per group and round, which cost more than the overlap
+  // returns (measured, see below).  Here the sweep is re-ordered into phases whose two halves are INDEPENDENT tournaments:
+  //   phase 1: round-robin inside the slot halves H1 = [0, P) and H2 = [P, 2P)               (P - 1 rounds, P/2 pairs each)
+  //   phase 2a: bipartite H1a x H2a and H1b x H2b (top stays, bottom shifts to the previous pair)   (P/2 rounds)
+  //   phase 2b: bipartite H1a x H2b and H1b x H2a                                                (P/2 rounds)
+  // = 2P - 1 rounds and every pair of blocks once, as before.  Each half runs on its own stream with no events inside a
+  // phase (the rotations of one half run under the GEMMs of the other); the LAST round of a phase writes the blocks where
+  // the next phase wants them (the permutation is only a table of C offsets of the update GEMM) and is bracketed by two
+  // stream barriers -- six per sweep.
+  const int H = P / 2;
+  bool phased = vfree && P >= 16 && (P % 4 == 0) && s_phase != nullptr && s_phase != s;
+  if (const char* ev = getenv("MPSK_SVD_PHASES")) { if (atoi(ev) == 0) phased = false; }
+  if (phased) {
+    int64_t* hph = huCV + 2 * P;           // follows the five 2P-entry arrays above
+    auto rr_local = [&](int pl_, int half, int Pi) -> int {       // dest_slot of the round-robin on Pi pairs
+      if (Pi == 1) return half;
+      if (half == 0) {
+        if (pl_ == 0) return 0;
+        if (pl_ + 1 <= Pi - 1) return 2 * (pl_ + 1);
+        return 2 * (Pi - 1) + 1;
+      }
+      if (pl_ == 0) return 2;
+      return 2 * (pl_ - 1) + 1;
+    };
+    auto t0 = [&](int pp, int half) -> int { const int inst = pp / H, pl_ = pp % H; return 2 * H * inst + rr_local(pl_, half, H); };
+    auto t2 = [&](int pp, int half) -> int {
+      if (half == 0) return 2 * pp;
+      const int inst = pp / H, pl_ = pp % H;
+      return 2 * (inst * H + (pl_ - 1 + H) % H) + 1;
+    };
+    for (int pp = 0; pp < P; ++pp)
+      for (int half = 0; half < 2; ++half) {
+        const int a = t0(pp, half);
+        int a_last;                          // phase 1 -> 2a: H1a -> tops of instance A, H1b -> tops of B, H2a / H2b -> bottoms
+        if (a < H) a_last = 2 * a;
+        else if (a < 2 * H) a_last = P + 2 * (a - H);
+        else if (a < 3 * H) a_last = 2 * (a - 2 * H) + 1;
+        else a_last = P + 2 * (a - 3 * H) + 1;
+        const int b = t2(pp, half);
+        const int q = b / 2;
+        const int b_lastA = (b & 1) ? 2 * ((q + H) % P) + 1 : b;          // 2a -> 2b: the bottoms change instance
+        const int b_lastB = (b & 1) ? P + q : q;                           // 2b -> phase 1: tops -> [0, P), bottoms -> [P, 2P)
+        const int dst[5] = {a, a_last, b, b_lastA, b_lastB};
+        for (int t = 0; t < 5; ++t) hph[(size_t)t * 2 * P + (size_t)half * P + pp] = (int64_t)dst[t] * JB * mm;
+      }
   }
   hipError_t e;
   if ((e = hipMemcpyAsync(tabs, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
@@ -492,7 +542,16 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     if ((e = hipEventCreateWithFlags(&evW[b], hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&evV[b], hipEventDisableTiming)) != hipSuccess) return e;
   }
-  auto drop_events = [&]() { for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(evW[b]); (void)hipEventDestroy(evV[b]); } };
+  hipEvent_t evPh[2] = {nullptr, nullptr}, evLag = nullptr;
+  if (phased) {
+    for (int b = 0; b < 2; ++b)
+      if ((e = hipEventCreateWithFlags(&evPh[b], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&evLag, hipEventDisableTiming)) != hipSuccess) return e;
+  }
+  auto drop_events = [&]() {
+    for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(evW[b]); (void)hipEventDestroy(evV[b]); if (evPh[b]) (void)hipEventDestroy(evPh[b]); }
+    if (evLag) { (void)hipEventDestroy(evLag); evLag = nullptr; }
+  };
   long rc = 0;                              // global round counter
   int vcur = 0;
   // V-free mode (mpsk_tsplit): nothing runs on s2, and the rotation kernel (latency-bound, one workgroup per pair) leaves
@@ -540,7 +599,60 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       (void)hipEventRecord(evS, s);
       for (int g2 = 1; g2 < NG; ++g2) (void)hipStreamWaitEvent(gst[g2], evS, 0);
     }
-    for (int r = 0; r < rounds; ++r, ++rc) {
+    if (phased) {
+      hipStream_t st[2] = {s, s_phase};
+      auto barrier = [&]() -> hipError_t {           // both halves have finished everything enqueued so far
+        hipError_t e2;
+        if ((e2 = hipEventRecord(evPh[0], st[0])) != hipSuccess) return e2;
+        if ((e2 = hipEventRecord(evPh[1], st[1])) != hipSuccess) return e2;
+        if ((e2 = hipStreamWaitEvent(st[0], evPh[1], 0)) != hipSuccess) return e2;
+        return hipStreamWaitEvent(st[1], evPh[0], 0);
+      };
+      auto half_round = [&](int inst, const int64_t* dest, double* Wb, hipEvent_t after_gram, hipEvent_t wait_first) -> hipError_t {
+        hipStream_t sg = st[inst];
+        const int p0 = inst * H, pn = H;
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.A = G[cur]; g.B = G[cur]; g.C = Mpart; g.M = J2; g.N = J2; g.lda = mm; g.ldb = mm; g.ldc = J2;
+        g.batch = pn * Q; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = 1; g.transB = 0;
+        g.tabA = t_gramA + (size_t)p0 * Q; g.tabB = g.tabA; g.tabC = t_gramC + (size_t)p0 * Q; g.tabs_even = kq_even;
+        g.K = kq;
+        hipError_t e2;
+        if (wait_first && (e2 = hipStreamWaitEvent(sg, wait_first, 0)) != hipSuccess) return e2;
+        if ((e2 = gemm_f64(g, sg)) != hipSuccess) return e2;
+        if (after_gram && (e2 = hipEventRecord(after_gram, sg)) != hipSuccess) return e2;
+        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(pn), dim3(256), 0, sg, Mpart + (size_t)p0 * Q * J2 * J2, Q,
+                           Wb + (size_t)p0 * J2 * J2, tol, flag, inner_sweeps);
+        GemmArgs u;
+        std::memset(&u, 0, sizeof(u));
+        u.B = Wb; u.N = J2; u.K = J2; u.ldb = J2; u.batch = pn; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
+        u.tabB = t_updB + p0; u.tabs_even = kq_even; u.splitN = JB;
+        u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G + p0;
+        u.tabC = dest + p0; u.tabC2 = dest + P + p0;
+        return gemm_f64(u, sg);
+      };
+      if ((e = barrier()) != hipSuccess) { drop_events(); drop_group_events(); return e; }      // (flag memset, previous sweep)
+      const int ph_rounds[3] = {2 * H - 1, H, H};
+      const int ph_norm[3] = {0, 2, 2}, ph_last[3] = {1, 3, 4};
+      for (int ph = 0; ph < 3; ++ph)
+        for (int r = 0; r < ph_rounds[ph]; ++r, ++rc) {
+          const bool last = (r == ph_rounds[ph] - 1);
+          double* Wb = Wm + (size_t)(rc & 1) * P * J2 * J2;
+          const int64_t* dest = t_phase + (size_t)(last ? ph_last[ph] : ph_norm[ph]) * 2 * P;
+          if (last && (e = barrier()) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+          // the two halves would march in lockstep (same durations, same start): half B starts a phase only when half A
+          // has finished its first Gram product, so that from then on B's GEMMs fall into A's rotation window and vice versa
+          const bool lag = (r == 0 && !last);
+          for (int inst = 0; inst < 2; ++inst)
+            if ((e = half_round(inst, dest, Wb, (lag && inst == 0) ? evLag : nullptr, (lag && inst == 1) ? evLag : nullptr)) != hipSuccess) {
+              drop_events(); drop_group_events(); return e;
+            }
+          if (last && (e = barrier()) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+          cur ^= 1;
+          vcur ^= 1;
+        }
+    }
+    for (int r = 0; r < (phased ? 0 : rounds); ++r, ++rc) {
       const int wb = (int)(rc & 1);
       double* Wb = Wm + (size_t)wb * P * J2 * J2;
       if (NG > 1) {
@@ -606,6 +718,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     }
     ++sweeps;
     if ((e = sync_groups()) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+    if (phased && (e = hipStreamSynchronize(s_phase)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
     if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
     if ((e = hipStreamSynchronize(s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
     double mx;
