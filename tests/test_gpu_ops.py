@@ -477,7 +477,7 @@ def test_qrlq_pair(be, m, n):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("m,n,k", [(512, 384, 100), (384, 512, 100), (1024, 1024, 256), (200, 130, 0)])
+@pytest.mark.parametrize("m,n,k", [(512, 384, 100), (384, 512, 100), (1024, 1024, 256), (200, 130, 0), (1536, 1280, 300)])
 def test_tsplit(be, m, n, k, mode):
     """mpsk_tsplit (V-free Jacobi + rebuilt factor): al, ar isometries, al c ar = the optimal rank-k truncation of theta
     (same singular values / discarded norm as numpy), c triangular, for both orientations and a graded spectrum."""
@@ -561,3 +561,39 @@ def test_device_ritz_step_matches_host(be):
             assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-11, (rank, m)
             assert b @ be.download(x0).ravel() > 0            # sign convention: positive overlap with the start vector
             assert abs(b @ M @ b - lam) < 1e-10 * max(1.0, abs(lam))
+
+
+def test_deferred_gauge_completion(be):
+    """mpsk_ctx_qr_defer / mpsk_qr_commit: the factorization returns once enqueued, workspace-free calls are accepted in
+    between, workspace users are refused, and after the commit the factors equal those of the immediate calls -- for a
+    well-conditioned pair, for an ill-conditioned matrix whose third pass is repeated at commit (redone bit), and for LQ."""
+    from mpskit_jl_amd._lib import MpskError
+    rng = np.random.default_rng(21)
+    m, n = 768, 256
+    A1 = rng.standard_normal((m, n))
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A2 = (U * np.logspace(0, -9, n)) @ V.T                       # cond 1e9: the first-order third pass is not enough
+    d1, d2 = be.upload(A1), be.upload(A2)
+    Qa, Ra = (be.download(t) for t in be.qrpos(d1))
+    Qb, Rb = (be.download(t) for t in be.qrpos(d2))
+    be.qr_defer()
+    Q1, R1, Q2, R2 = be.qrpos2(d1, d2)
+    spec = be.gemm(Q1, R1)                                        # workspace-free: accepted while the pair is pending
+    with pytest.raises(MpskError):
+        be.qrpos(d1)                                              # needs the ctx workspace: refused until the commit
+    redone = be.qr_commit()
+    assert redone in (0, 1, 2, 3) and not (redone & 1)            # the well-conditioned factor is final at the enqueue
+    assert relerr(be.download(spec), A1) < 1e-13
+    assert relerr(be.download(Q1), Qa) < 1e-12 and relerr(be.download(R1), Ra) < 1e-12
+    assert relerr(be.download(Q2), Qb) < 1e-7 and relerr(be.download(R2), Rb) < 1e-9
+    q2 = be.download(Q2)
+    assert np.abs(q2.T @ q2 - np.eye(n)).max() < 1e-13
+    assert be.qr_commit() == 0                                    # nothing pending: a no-op
+    B = A1.T.copy()                                               # 256 x 768
+    La, Qla = (be.download(t) for t in be.lqpos(be.upload(B)))
+    be.qr_defer()
+    L, Ql = be.lqpos(be.upload(B))
+    be.gemm(Q1, R1)
+    be.qr_commit()
+    assert relerr(be.download(L), La) < 1e-12 and relerr(be.download(Ql), Qla) < 1e-12
