@@ -228,8 +228,7 @@ def main():
         achieved = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(achieved, 3),
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                    "launches": top["launches"], "launches_sampled": "both stage launches of every 4th matvec (the HIP event pair costs ~10 us of stream time per launch)",
-                    "avg_ms": round(top["avg_ms"], 5),
+                    "launches": top["launches"], "avg_ms": round(top["avg_ms"], 5),
                     "flops_per_launch": top["flops"] / top["launches"], "traffic": None}
         # HBM-side bytes per launch of that kernel from the separate rocprofv3 --pmc passes of tools/pmc_quick.sh
         # (FETCH_SIZE / WRITE_SIZE cannot share a pass with anything else; D = 1024 north-star point).  Attached only

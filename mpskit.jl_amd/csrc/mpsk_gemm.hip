@@ -669,7 +669,7 @@ struct ProfRec { hipEvent_t e0, e1; double flops; int bm, bn, aligned, sk, zs; }
 // distinct ctxs may launch from distinct host threads.
 static std::atomic<bool> g_prof_on{false};
 static std::atomic<uint64_t> g_prof_seq{0};
-static const int g_prof_stride = getenv("MPSK_PROF_STRIDE") && atoi(getenv("MPSK_PROF_STRIDE")) > 0 ? atoi(getenv("MPSK_PROF_STRIDE")) : 4;
+static const int g_prof_stride = getenv("MPSK_PROF_STRIDE") && atoi(getenv("MPSK_PROF_STRIDE")) > 0 ? atoi(getenv("MPSK_PROF_STRIDE")) : 1;
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 
@@ -723,7 +723,7 @@ static hipError_t launch_one(K kern, std::atomic<uint64_t>& attr, dim3 grid, siz
                              bool prof, ProfRec* r) {
   if (hipError_t e = ensure_dyn_smem(attr, reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return e;
   if (prof) {
-    (void)hipEventCreate(&r->e0); (void)hipEventCreate(&r->e1);
+    (void)hipEventCreateWithFlags(&r->e0, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&r->e1, hipEventDisableSystemFence);   // device-scope release: no system-wide cache flush per record
     (void)hipEventRecord(r->e0, s);
   }
   hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, s, g);
@@ -740,9 +740,10 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   const bool zs = g.zsegA != nullptr;
   if (zs && !(g.tag == 1 && !TA && !TB && g.zsegB != nullptr)) return hipErrorInvalidValue;   // tables: tagged NN launches only
   const bool tagged = (g.tag == 1 && !TA && !TB);
-  // the event pair around a launch costs a ~10 us gap on the stream (measured in the kernel trace of bench.py: 10.3 us
-  // between stage 1 and stage 3 with the profile on, < 3 us without): the profile therefore samples BOTH stage launches of
-  // every g_prof_stride-th matvec (tagged launches come in pairs) instead of all of them
+  // an event pair created with the default flags costs a ~10 us gap on the stream per launch (system-scope release on
+  // every record; kernel trace of bench.py: 10.3 us between stage 1 and stage 3 with the profile on, < 3 us without).
+  // With hipEventDisableSystemFence the cost is not measurable (same-box A/B, 0.643 vs 0.644 sweeps/s), so every tagged
+  // launch is recorded; MPSK_PROF_STRIDE=n samples both stage launches of every n-th matvec instead
   bool prof = tagged && g_prof_on.load(std::memory_order_relaxed);
   if (prof) {
     const uint64_t n = g_prof_seq.fetch_add(1, std::memory_order_relaxed);

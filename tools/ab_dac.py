@@ -32,7 +32,7 @@ for a in (sys.argv[1:] or ["1024,2"]):
         best = min(best, e0.elapsed_time(e1) / n)
     print(f"{os.environ.get('MPSK_LIB', 'libmpsk.so')}: D={D} d={d}: {best:.4f} ms  {flops_dAC(D, d, W) / best * 1e-9:.2f} TFLOP/s (algorithmic)", flush=True)
     be.prof_enable(True)
-    for _ in range(40):          # the profile samples every 4th matvec
+    for _ in range(10):
         h(x, out=y)
     for r_ in be.prof_summary():
         print(f"    {r_['kernel']}: {r_['avg_ms']*1e3:.1f} us  {r_['flops']/r_['launches']/r_['avg_ms']*1e-9:.1f} TF/s")
