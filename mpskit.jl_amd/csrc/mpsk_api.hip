@@ -129,12 +129,12 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
   HIPCHK(hipHostMalloc(&c->h_scal, sizeof(double) * MAXK, hipHostMallocDefault));
   HIPCHK(hipMalloc(&c->d_coef, sizeof(double) * MAXK));
   HIPCHK(hipHostMalloc(&c->h_coef, sizeof(double) * MAXK, hipHostMallocDefault));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_coef, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_coef, hipEventDisableTiming | hipEventDisableSystemFence));
   HIPCHK(hipMalloc(&c->d_flag, 64));
   HIPCHK(hipHostMalloc(&c->h_flags, 64, hipHostMallocDefault));
   HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
   *out = c;
   return MPSK_OK;
 }
@@ -739,7 +739,7 @@ int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr
       for (; k < ns; ++k) { tab[(size_t)t * ns + k] = 0; tab[(size_t)(d + t) * ns + k] = (int64_t)nc * slabR; }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h->zseg, tab.data(), sizeof(int64_t) * tab.size(), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e == hipSuccess) e = hipEventRecord(h->ev_up, c->stream);
     if (e != hipSuccess) { c->pool[h->pool_idx].used = false; delete h; return fail(MPSK_ERR_HIP, hipGetErrorString(e)); }
   }

@@ -539,14 +539,14 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   if (!s2) s2 = s;
   hipEvent_t evW[2], evV[2];
   for (int b = 0; b < 2; ++b) {
-    if ((e = hipEventCreateWithFlags(&evW[b], hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&evV[b], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&evW[b], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&evV[b], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
   }
   hipEvent_t evPh[2] = {nullptr, nullptr}, evLag = nullptr;
   if (phased) {
     for (int b = 0; b < 2; ++b)
-      if ((e = hipEventCreateWithFlags(&evPh[b], hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&evLag, hipEventDisableTiming)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&evPh[b], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&evLag, hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
   }
   auto drop_events = [&]() {
     for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(evW[b]); (void)hipEventDestroy(evV[b]); if (evPh[b]) (void)hipEventDestroy(evPh[b]); }
@@ -580,8 +580,8 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   if (NG > 1) {
     for (int b = 0; b < 2; ++b)
       for (int g2 = 0; g2 < NG; ++g2)
-        if ((e = hipEventCreateWithFlags(&evU[b][g2], hipEventDisableTiming)) != hipSuccess) { drop_events(); return e; }
-    if ((e = hipEventCreateWithFlags(&evS, hipEventDisableTiming)) != hipSuccess) { drop_events(); return e; }
+        if ((e = hipEventCreateWithFlags(&evU[b][g2], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) { drop_events(); return e; }
+    if ((e = hipEventCreateWithFlags(&evS, hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) { drop_events(); return e; }
   }
   auto drop_group_events = [&]() {
     if (NG > 1) {
