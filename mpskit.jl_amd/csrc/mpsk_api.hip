@@ -1484,8 +1484,8 @@ int mpsk_vnormalize_dev(mpsk_ctx* c, int64_t n, const void* x, void* y, void* de
   double* n2 = dev_n2 ? (double*)dev_n2 : c->d_scal + (MAXK - 1);
   const double* xs[1] = {(const double*)x};
   HIPCHK(vec_multidot(xs, 1, (const double*)x, n, n2, c->d_partial, c->stream));
-  if (y != x) HIPCHK(hipMemcpyAsync(y, x, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(vec_scal_rsqrt_dev(n2, (double*)y, n, c->stream));
+  if (y != x) HIPCHK(vec_scal_rsqrt_dev_oop(n2, (const double*)x, (double*)y, n, c->stream));
+  else HIPCHK(vec_scal_rsqrt_dev(n2, (double*)y, n, c->stream));
   return MPSK_OK;
 }
 

@@ -120,6 +120,7 @@ hipError_t vec_axpby(double a, const double* x, double b, double* y, int64_t n, 
 hipError_t vec_times_i(const double* x, double* y, int64_t n, hipStream_t s);
 hipError_t vec_scal(double a, double* x, int64_t n, hipStream_t s);
 hipError_t vec_scal_rsqrt_dev(const double* d_n2, double* x, int64_t n, hipStream_t s);
+hipError_t vec_scal_rsqrt_dev_oop(const double* d_n2, const double* x, double* y, int64_t n, hipStream_t s);
 // CGS2 of y against xs[0..k) + squared norm of the remainder, fused passes (mpsk_ops.hip); d_out = {h1[k], h2[k], |y|^2}
 hipError_t vec_cgs2(const double* const* xs, int k, double* y, int64_t n, double* d_out, double* d_partial, hipStream_t s);
 // Ritz step of a fixed-budget Krylov solve on the device (mpsk_ops.hip: ritz_small_kernel); m <= 32

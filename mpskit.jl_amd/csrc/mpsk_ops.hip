@@ -401,6 +401,22 @@ __global__ __launch_bounds__(256) void scal_rsqrt_dev_kernel(const double* __res
     x[e] *= a;
 }
 
+// y = x / sqrt(*d_n2), out of place (one pass instead of a device copy followed by the in-place scaling)
+__global__ __launch_bounds__(256) void scal_rsqrt_dev_oop_kernel(const double* __restrict__ d_n2, const double* __restrict__ x,
+                                                                 double* __restrict__ y, int64_t n) {
+  const double n2 = *d_n2;
+  const double a = (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    y[e] = a * x[e];
+}
+hipError_t vec_scal_rsqrt_dev_oop(const double* d_n2, const double* x, double* y, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(scal_rsqrt_dev_oop_kernel, dim3((int)nb), dim3(256), 0, s, d_n2, x, y, n);
+  return hipGetLastError();
+}
+
 hipError_t vec_scal_rsqrt_dev(const double* d_n2, double* x, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   int64_t nb = (n + 255) / 256;
