@@ -185,6 +185,14 @@ int mpsk_lqpos(mpsk_ctx* ctx, int m, int n, const void* A, int lda, void* L, int
  * two calls only entry points that do not use the ctx workspace are accepted (mpsk_gemm, mpsk_v*): the DMRG sweep
  * enqueues the galerkin evaluation of the site there (toolbox.jl:17-22), so the stream has work while the host waits. */
 int mpsk_ctx_qr_defer(mpsk_ctx* ctx);
+/* Side stream: mpsk_ctx_side_mark records "now" on the ctx stream; after mpsk_ctx_side_begin every mpsk_* call of the ctx
+ * runs on its second stream, ordered after the mark only; mpsk_ctx_side_end switches back and makes the main stream wait
+ * for the side work.  Workspace users and the calls that use the second stream themselves (mpsk_qrpos2, mpsk_qrlq_pair,
+ * mpsk_tsplit) are refused in between.  The sweep runs the galerkin evaluation of a left-moving visit there, under the
+ * latency-bound CholeskyQR chain of the LQ step it has just enqueued on the main stream. */
+int mpsk_ctx_side_mark(mpsk_ctx* ctx);
+int mpsk_ctx_side_begin(mpsk_ctx* ctx);
+int mpsk_ctx_side_end(mpsk_ctx* ctx);
 int mpsk_qr_commit(mpsk_ctx* ctx, int* redone);
 /* thin SVD of theta (m x n): theta = U diag(S) Vh, S descending.  U: m x kmax, S: kmax, Vh: kmax x n
  * buffers with kmax = min(m, n).  Truncation (TensorKit truncdim & truncerr, dmrg.jl:75,96):

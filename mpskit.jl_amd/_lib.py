@@ -96,6 +96,9 @@ SIGNATURES = {
     "mpsk_vnormalize_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vnrm2_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "mpsk_ctx_qr_defer": [C.c_void_p],
+    "mpsk_ctx_side_mark": [C.c_void_p],
+    "mpsk_ctx_side_begin": [C.c_void_p],
+    "mpsk_ctx_side_end": [C.c_void_p],
     "mpsk_qr_commit": [C.c_void_p, C.POINTER(C.c_int)],
     "mpsk_vritz_dev": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vlincomb_dev": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, C.c_void_p],

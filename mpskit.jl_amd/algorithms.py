@@ -5,6 +5,7 @@ every flop happens inside libmpsk."""
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -184,6 +185,13 @@ def find_groundstate(psi, H, alg=None, envs=None):
     raise TypeError(f"unknown algorithm {alg!r}")
 
 
+# Galerkin evaluation of left-moving visits on the ctx's second stream (mpsk_ctx_side_*), under the CholeskyQR chain of the
+# LQ step.  MEASURED AND LEFT OFF (MI355X, same-box A/B of bench.py, three runs each): 0.6458 / 0.6413 / 0.6466 sweeps/s with
+# it, 0.6476 / 0.6442 / 0.6472 without -- the GEMMs of the projection delay the latency-bound step kernels they run beside
+# by as much as they hide (the same outcome as the two-stream Jacobi schedule of mpsk_tsplit).  MPSK_SIDE_STREAM=1 enables it.
+_SIDE_STREAM = os.environ.get("MPSK_SIDE_STREAM", "0") == "1"
+
+
 def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
     """One full DMRG sweep, pos in [1:L-1; L:-1:2] (dmrg.jl:33-38): per site one eigsolve with the
     effective Hamiltonian, one galerkin evaluation, and the lazy gauge / environment updates that
@@ -211,7 +219,8 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
         # Deferred gauge step (mpsk_ctx_qr_defer / mpsk_qr_commit) on left-moving visits: the LQ factorization the NEXT
         # visit needs is enqueued first, the galerkin evaluation of this visit (which does not depend on it) behind it,
         # and only then does the host wait for the factorization's success flag -- the stream has ~0.2 ms of work while
-        # it does (the flag read-back used to leave the GPU idle for ~40 us per visit).  Same tensors, same operations.
+        # it does (the flag read-back used to leave the GPU idle for ~40 us per visit); the evaluation itself runs on the
+        # ctx's second stream, under the latency-bound factorization chain.  Same tensors, same operations.
         qdef = defer and hasattr(be, "qr_defer") and not psi.cplx
         if psi.ALs[pos] is None and pos < L - 1:
             # right-moving visit: leftorth(old AC) (galerkin projector) and leftorth(new AC) (next AL)
@@ -228,10 +237,18 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
             # that the galerkin evaluation runs behind it
             al_old = psi.AL(pos)
             psi.set_AC(pos, vec)
+            side = False
             if qdef and pos > 0:
+                side = hasattr(be, "side_begin") and _SIDE_STREAM
+                if side:
+                    be.side_mark()          # the galerkin evaluation depends on nothing enqueued after this point
                 be.qr_defer()
                 psi.AR(pos)
+                if side:
+                    be.side_begin()         # ... so it runs on the second stream, under the CholeskyQR chain of the LQ step
             e = _galerkin(be, h, ac_old, al_old, g, gslot, iv)
+            if side:
+                be.side_end()
             if qdef:
                 be.qr_commit()
         if not defer:

@@ -387,6 +387,16 @@ class Backend:
         """the next qrpos2 / lqpos returns once enqueued; finish it with qr_commit (include/mpsk.h)."""
         check(self.lib.mpsk_ctx_qr_defer(self.ctx), "mpsk_ctx_qr_defer")
 
+    def side_mark(self):
+        check(self.lib.mpsk_ctx_side_mark(self.ctx), "mpsk_ctx_side_mark")
+
+    def side_begin(self):
+        """route the following calls to the ctx's second stream, ordered after side_mark() only (include/mpsk.h)."""
+        check(self.lib.mpsk_ctx_side_begin(self.ctx), "mpsk_ctx_side_begin")
+
+    def side_end(self):
+        check(self.lib.mpsk_ctx_side_end(self.ctx), "mpsk_ctx_side_end")
+
     def qr_commit(self) -> int:
         r = C.c_int(0)
         check(self.lib.mpsk_qr_commit(self.ctx, C.byref(r)), "mpsk_qr_commit")

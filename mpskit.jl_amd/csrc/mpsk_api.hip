@@ -87,6 +87,7 @@ struct mpsk_ctx {
     void *L = nullptr, *Qo = nullptr; int ldl = 0, ldqo = 0;
   } pend;
   bool defer_next = false;
+  bool on_side = false;         // mpsk_ctx_side_begin .. mpsk_ctx_side_end: `stream` and `stream2` are swapped
   std::map<std::pair<const mpsk_mposlice*, const mpsk_mposlice*>, MixPlan> pair_plans;
   std::vector<PoolBuf> pool;    // device buffers of prepared operators (mpsk_hac), reused across site visits
 };
@@ -386,6 +387,7 @@ int mpsk_mposlice_dims(const mpsk_mposlice* s, int* Wl, int* Wr, int* d) {
 // --------------------------------------------------------------------------------------------
 static int ensure_ws(mpsk_ctx* c, size_t bytes) {
   if (c->pend.active) return fail(MPSK_ERR_INVALID, "a deferred factorization still owns the workspace: call mpsk_qr_commit first");
+  if (c->on_side) return fail(MPSK_ERR_INVALID, "workspace users are not accepted on the side stream: call mpsk_ctx_side_end first");
   if (bytes <= c->ws_bytes) return MPSK_OK;
   return mpsk_ctx_workspace_reserve(c, bytes + bytes / 4);
 }
@@ -1124,6 +1126,38 @@ static int lqpos_complete(mpsk_ctx* c, int* redone) {
   HIPCHK(transpose(P.Rt, P.m, P.m, P.m, (double*)P.L, P.ldl, c->stream));
   if (redone) *redone = 0;                     // L / Q are only written here: nothing speculative to redo
   (void)r1;
+  return MPSK_OK;
+}
+
+// Side stream.  mpsk_ctx_side_mark records "now" on the ctx stream; mpsk_ctx_side_begin makes the ctx's second stream wait
+// for that mark and routes every following mpsk_* call to it; mpsk_ctx_side_end routes calls back to the main stream, which
+// waits for the side work.  The sweep marks, enqueues the (latency-bound, mostly idle) CholeskyQR chain of the next gauge
+// step on the main stream, and runs the site's galerkin evaluation on the side stream underneath it.  Calls that use the
+// second stream themselves (mpsk_qrpos2, mpsk_qrlq_pair, mpsk_tsplit) or the ctx workspace are refused in between.
+int mpsk_ctx_side_mark(mpsk_ctx* c) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE(!c->on_side, "already on the side stream");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+  return MPSK_OK;
+}
+int mpsk_ctx_side_begin(mpsk_ctx* c) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE(!c->on_side, "already on the side stream");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  std::swap(c->stream, c->stream2);
+  c->on_side = true;
+  return MPSK_OK;
+}
+int mpsk_ctx_side_end(mpsk_ctx* c) {
+  REQUIRE(c, "ctx is NULL");
+  if (!c->on_side) return MPSK_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->ev_join, c->stream));          // (the side stream)
+  std::swap(c->stream, c->stream2);
+  c->on_side = false;
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return MPSK_OK;
 }
 

@@ -301,6 +301,15 @@ class CpuBackend:
     def qr_defer(self):
         pass
 
+    def side_mark(self):
+        pass
+
+    def side_begin(self):
+        pass
+
+    def side_end(self):
+        pass
+
     def qr_commit(self):
         return 0
 
