@@ -291,4 +291,40 @@ function orth_step!(basis::Vector{<:ROCTensor}, y::ROCTensor)
     return h, beta[]
 end
 
+# ---- fixed-budget :SR solve without a host synchronisation (what mpskit.jl_amd/krylov.py does with values = false) ----
+# KrylovKit's eigsolve decides convergence on the host after every step; for `Arnoldi(; krylovdim = m, maxiter = 1)` with a
+# fixed number of steps nothing has to be decided, so the recurrence, the Ritz step of the projected matrix and the assembly of
+# the Ritz vector can all stay on the device.  `slot` holds the (2k+1) scalars of every step, `buf` the Ritz coefficients.
+function fixedpoint_fixed_budget(h::ROCddAC, x0::ROCTensor, m::Int)
+    @assert 1 <= m <= 32
+    stride = 2m + 1
+    slot = ROCTensor((m * stride,)); buf = ROCTensor((40,))
+    V = [ROCTensor(x0.dims; cplx=x0.cplx) for _ in 1:(m + 1)]
+    check(ccall((:mpsk_vnormalize_dev, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        CTX[], nreal(x0), x0.ptr, V[1].ptr, C_NULL))
+    for k in 1:m
+        h(V[k + 1], V[k])                                   # mpsk_hac_apply
+        ptrs = Ptr{Cvoid}[v.ptr for v in V[1:k]]
+        check(ccall((:mpsk_vorth_step_dev, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cvoid}),
+            CTX[], nreal(x0), k, ptrs, V[k + 1].ptr, slot.ptr + 8 * (k - 1) * stride))
+    end
+    check(ccall((:mpsk_vritz_dev, libmpsk[]), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        CTX[], m, stride, slot.ptr, buf.ptr, buf.ptr + 8 * 32))
+    y = ROCTensor(x0.dims; cplx=x0.cplx)
+    ptrs = Ptr{Cvoid}[v.ptr for v in V[1:m]]
+    check(ccall((:mpsk_vlincomb_dev, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cvoid}),
+        CTX[], nreal(x0), m, ptrs, buf.ptr, y.ptr))
+    check(ccall((:mpsk_vnormalize_dev, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        CTX[], nreal(x0), y.ptr, y.ptr, C_NULL))
+    return y                                                # eigenvalue / residual estimate: buf[33:35] (device)
+end
+
+# ---- deferred completion of a gauge step (the left-moving DMRG visit: LQ of the new AC, galerkin evaluation, commit) ----
+qr_defer() = check(ccall((:mpsk_ctx_qr_defer, libmpsk[]), Cint, (Ptr{Cvoid},), CTX[]))
+function qr_commit()
+    redone = Ref{Cint}(0)
+    check(ccall((:mpsk_qr_commit, libmpsk[]), Cint, (Ptr{Cvoid}, Ref{Cint}), CTX[], redone))
+    return redone[]
+end
+
 end # module
