@@ -299,11 +299,12 @@ function fixedpoint_fixed_budget(h::ROCddAC, x0::ROCTensor, m::Int)
     @assert 1 <= m <= 32
     stride = 2m + 1
     slot = ROCTensor((m * stride,)); buf = ROCTensor((40,))
-    V = [ROCTensor(x0.dims; cplx=x0.cplx) for _ in 1:(m + 1)]
+    V = Vector{typeof(x0)}(undef, m + 1)
+    V[1] = ROCTensor(x0.dims; cplx=x0.cplx)
     check(ccall((:mpsk_vnormalize_dev, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
         CTX[], nreal(x0), x0.ptr, V[1].ptr, C_NULL))
     for k in 1:m
-        h(V[k + 1], V[k])                                   # mpsk_hac_apply
+        V[k + 1] = h(V[k])                                  # mpsk_hac_apply
         ptrs = Ptr{Cvoid}[v.ptr for v in V[1:k]]
         check(ccall((:mpsk_vorth_step_dev, libmpsk[]), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cvoid}),
             CTX[], nreal(x0), k, ptrs, V[k + 1].ptr, slot.ptr + 8 * (k - 1) * stride))
