@@ -206,6 +206,7 @@ def main():
         alg.dmrg_sweep(psi, H, envs, eig, ws)
     be.prof_enable(True)
     qr0 = be.qr_stats()
+    qr_retry0 = be.qr_retries()
     barrier()
     t0 = time.perf_counter()
     eps = None
@@ -215,6 +216,7 @@ def main():
     dt = time.perf_counter() - t0
     be.prof_enable(False)
     qr_timed = {k: be.qr_stats()[k] - qr0[k] for k in qr0}
+    qr_timed["shift_retries"] = be.qr_retries() - qr_retry0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=be.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

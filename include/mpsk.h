@@ -77,6 +77,9 @@ int mpsk_ctx_workspace_reserve(mpsk_ctx* ctx, size_t bytes);   /* pre-size the p
  * flagged inputs finished by the robust CholeskyQR variant (any pointer may be NULL). */
 int mpsk_ctx_set_qr_mode(mpsk_ctx* ctx, int mode);
 int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallback, long* n_robust);
+/* CholeskyQR3 factorizations whose first attempt (shift at the rounding level of the Gram matrix) broke down and that were
+ * repeated with the shift of Fukaya et al. (s = 11 (mn + n(n+1)) u ||A||_F^2); counted in n_chol when the repeat succeeds */
+int mpsk_ctx_qr_retries(mpsk_ctx* ctx, long* n_retry);
 /* tsvd algorithm switch: 0 = Jacobi on theta directly; 1 = the tall orientation of theta is factored with QRpos first and
  * the block-Jacobi iteration runs on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra); 2 (default)
  * = additionally R^T = Q1 R1 and the iteration runs on R1^T (mpsk_tsplit only: 15 -> 10 sweeps on graded 4096^2 tensors;

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mpsk_vlincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, c_double_p, C.c_void_p],
     "mpsk_vnormalize_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vnrm2_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "mpsk_ctx_qr_retries": [C.c_void_p, C.POINTER(C.c_long)],
     "mpsk_ctx_qr_defer": [C.c_void_p],
     "mpsk_ctx_side_mark": [C.c_void_p],
     "mpsk_ctx_side_begin": [C.c_void_p],

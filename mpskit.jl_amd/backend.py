@@ -80,6 +80,12 @@ class Backend:
     def set_qr_mode(self, mode):
         check(self.lib.mpsk_ctx_set_qr_mode(self.ctx, int(mode)), "mpsk_ctx_set_qr_mode")
 
+    def qr_retries(self) -> int:
+        """CholeskyQR3 factorizations repeated with the published shift after a breakdown of the rounding-level one."""
+        r = C.c_long(0)
+        check(self.lib.mpsk_ctx_qr_retries(self.ctx, C.byref(r)), "mpsk_ctx_qr_retries")
+        return r.value
+
     def qr_stats(self):
         a, b, f, r = C.c_long(), C.c_long(), C.c_long(), C.c_long()
         check(self.lib.mpsk_ctx_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(f), C.byref(r)), "mpsk_ctx_qr_stats")

@@ -67,7 +67,9 @@ struct mpsk_ctx {
   int svd_precondition = 2;     // mpsk_ctx_set_svd_mode: 0 plain, 1 QR-preconditioned, 2 QR + QR of R^T (mpsk_tsplit; mpsk_tsvd treats it as 1)
   int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
   int* d_flag = nullptr;
-  long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0, n_qr_robust = 0;
+  long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0, n_qr_robust = 0, n_qr_retry = 0;
+  // first attempt of CholeskyQR3 with shift = qr_shift_fast * (bound of Fukaya et al.); a flagged breakdown repeats it with the bound
+  double qr_shift_fast = getenv("MPSK_CQ_SHIFT_SCALE") ? atof(getenv("MPSK_CQ_SHIFT_SCALE")) : 1.0e-8;
   // second stream + workspace for two concurrent factorizations (mpsk_qrpos2)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -966,9 +968,15 @@ static int qrpos_dispatch(mpsk_ctx* c, int m, int n, const double* A, int lda, d
   std::string err;
   if (c->qr_mode != 1 && n > 64) {
     int flag = 0;
-    hipError_t e = cholqr3(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream);
+    hipError_t e = cholqr3(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream, c->qr_shift_fast);
     if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3: ") + hipGetErrorString(e));
     if (flag == 0) { c->n_qr_chol++; return MPSK_OK; }
+    if (c->qr_shift_fast < 1.0) {          // breakdown with the rounding-level shift: the published shift next
+      c->n_qr_retry++;
+      e = cholqr3(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream, 1.0);
+      if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 (retry): ") + hipGetErrorString(e));
+      if (flag == 0) { c->n_qr_chol++; return MPSK_OK; }
+    }
     if (c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
     c->n_qr_fallback++;
     // second line of defence, still on the GEMM core: perturbed, repeatedly shifted CholeskyQR
@@ -1002,6 +1010,12 @@ int mpsk_ctx_qr_stats(mpsk_ctx* c, long* n_chol, long* n_house, long* n_fallback
   return MPSK_OK;
 }
 
+int mpsk_ctx_qr_retries(mpsk_ctx* c, long* n_retry) {
+  REQUIRE(c && n_retry, "NULL argument");
+  *n_retry = c->n_qr_retry;
+  return MPSK_OK;
+}
+
 int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
   REQUIRE(c && A && Q && R, "NULL argument");
   REQUIRE(m >= n && n > 0, "needs m >= n > 0");
@@ -1023,9 +1037,15 @@ static int qr_complete_one(mpsk_ctx* c, int m, int n, const double* A, int lda, 
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 finalize: ") + hipGetErrorString(e));
   if (redone) *redone = (pre != 0);
   if (*h_flag == 0) { c->n_qr_chol++; return MPSK_OK; }
+  int flag = 0;
+  if (c->qr_shift_fast < 1.0) {            // breakdown with the rounding-level shift: the published shift next
+    c->n_qr_retry++;
+    e = cholqr3(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream, 1.0);
+    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 (retry): ") + hipGetErrorString(e));
+    if (flag == 0) { c->n_qr_chol++; return MPSK_OK; }
+  }
   if (c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
   c->n_qr_fallback++;
-  int flag = 0;
   e = cholqr_robust(m, n, A, lda, Q, ldq, R, ldr, ws, c->d_flag, &flag, c->stream);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr_robust: ") + hipGetErrorString(e));
   if (flag == 0) { c->n_qr_robust++; return MPSK_OK; }
@@ -1053,7 +1073,16 @@ static int qrpos2_complete(mpsk_ctx* c, int* redone) {
   HIPCHK(hipEventRecord(c->ev_join, c->stream2));
   HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   r2 = (pre2 != 0);
-  if (c->h_flags[1] == 0) c->n_qr_chol++;
+  bool ok2 = (c->h_flags[1] == 0);
+  if (!ok2 && c->qr_shift_fast < 1.0) {    // (main stream, c->ws: the first factorization is complete)
+    c->n_qr_retry++;
+    int flag = 0;
+    hipError_t e3 = cholqr3(P.m, P.n, (const double*)P.A2, P.lda2, (double*)P.Q2, P.ldq2, (double*)P.R2, P.ldr2,
+                            (double*)c->ws, c->d_flag, &flag, c->stream, 1.0);
+    if (e3 != hipSuccess) return fail(MPSK_ERR_HIP, "cholqr3 (pair retry) failed");
+    ok2 = (flag == 0);
+  }
+  if (ok2) c->n_qr_chol++;
   else {
     if (c->qr_mode == 2) return fail(MPSK_ERR_INVALID, "cholqr3: matrix too ill-conditioned / rank deficient");
     c->n_qr_fallback++;
@@ -1103,10 +1132,10 @@ int mpsk_qrpos2(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1, i
   HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
   c->h_flags[0] = c->h_flags[1] = 0;
   hipError_t e = cholqr3_enqueue(m, n, (const double*)A1, lda1, (double*)Q1, ldq1, (double*)R1, ldr1, (double*)c->ws,
-                                 c->d_flag, &c->h_flags[0], c->stream);
+                                 c->d_flag, &c->h_flags[0], c->stream, c->qr_shift_fast);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 (1): ") + hipGetErrorString(e));
   e = cholqr3_enqueue(m, n, (const double*)A2, lda2, (double*)Q2, ldq2, (double*)R2, ldr2, (double*)c->ws2,
-                      c->d_flag + 8, &c->h_flags[1], c->stream2);
+                      c->d_flag + 8, &c->h_flags[1], c->stream2, c->qr_shift_fast);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3 (2): ") + hipGetErrorString(e));
   mpsk_ctx::PendingQR& P = c->pend;
   P.active = 1; P.m = m; P.n = n;
@@ -1230,7 +1259,7 @@ int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int l
   HIPCHK(transpose((const double*)A, lda, m, n, At, n, c->stream));
   if (defer && c->qr_mode != 1 && m > 64) {
     c->h_flags[0] = 0;
-    hipError_t e = cholqr3_enqueue(n, m, At, n, Qt, n, Rt, m, ws2, c->d_flag, &c->h_flags[0], c->stream);
+    hipError_t e = cholqr3_enqueue(n, m, At, n, Qt, n, Rt, m, ws2, c->d_flag, &c->h_flags[0], c->stream, c->qr_shift_fast);
     if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("cholqr3: ") + hipGetErrorString(e));
     mpsk_ctx::PendingQR& P = c->pend;
     P.active = 2; P.m = m; P.n = n; P.At = At; P.Qt = Qt; P.Rt = Rt; P.ws = ws2;

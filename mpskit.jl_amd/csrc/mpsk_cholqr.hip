@@ -12,6 +12,11 @@
 // (profiles/r01_*); the latency-bound Cholesky chain (32 launches x ~29 us) is about half of that.  Cholesky yields diag(R) > 0 directly, which is the QRpos convention
 // (TensorKit leftorth!(; alg = QRpos())); for a full-column-rank matrix the factorisation is unique,
 // so this agrees with Householder QRpos to O(cond * eps).
+// Shift policy: the bound of Fukaya et al. (s = 11 (mn + n(n+1)) u ||A||^2) is a worst-case constant, ~1e7 u here; a shift
+// that large leaves cond(Q1) ~ sqrt(s) / sigma_min, and on the benchmark sweep 28 % of the factorizations then needed a full
+// third Cholesky pass.  The callers (mpsk_api.hip) therefore try shift_scale * s with shift_scale = 1e-8 first (a shift at
+// the rounding level of the Gram matrix: 2 % repeats, no breakdown on the benchmark states) and repeat the factorization
+// with the published shift when the device flags a breakdown; MPSK_CQ_SHIFT_SCALE overrides the first attempt's scale.
 // Robustness: the first pass is shifted (Fukaya et al., "Shifted Cholesky QR", SIAM J. Sci. Comput.
 // 2020: s = 11 (mn + n(n+1)) u ||A||^2) which covers cond(A) up to ~1e15; a non-positive pivot
 // or a last-pass Gram matrix far from the identity raises a device flag and the caller falls back
@@ -398,7 +403,8 @@ static GemmArgs cq_mk(const double* A, const double* B, double* C, int M, int N,
 
 // One CholeskyQR pass.  X: m x n (ldx).  Writes Q (m x n, ldq) and the npad x npad upper factor Rp.
 static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, double* Q, int ldq, double* Rp,
-                          double* Rinv, double* T, bool shifted, bool check_identity, int* flag, hipStream_t s) {
+                          double* Rinv, double* T, bool shifted, bool check_identity, int* flag, hipStream_t s,
+                          double shift_scale = 1.0) {
   hipError_t e;
   double* Gw = T;                                                            // Gram matrix, consumed by the factorization
   GemmArgs g = cq_mk(X, X, Gw, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X: only the upper block triangle
@@ -408,7 +414,7 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
   if (check_identity) hipLaunchKernelGGL(cq_check_identity_kernel, dim3(256), dim3(256), 0, s, Gw, npad, n, 0.5, flag);
   if (shifted) {
     const double u = 1.1102230246251565e-16;
-    const double factor = 11.0 * ((double)m * n + (double)n * (n + 1)) * u;
+    const double factor = shift_scale * 11.0 * ((double)m * n + (double)n * (n + 1)) * u;
     hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, s, Gw, npad, n, factor);
   }
   const int nb = npad / CB;
@@ -524,11 +530,11 @@ static void cq_dbg_count(bool rep) {
   if (n % 100 == 0) fprintf(stderr, "[cholqr3] %ld factorizations, %ld repeated the third pass (thr %.1e)\n", n, r, CQ_FIRSTORDER_MAX);
 }
 hipError_t cholqr3_enqueue(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
-                           int* d_flag, int* flag_out, hipStream_t s) {
+                           int* d_flag, int* flag_out, hipStream_t s, double shift_scale) {
   const CqBufs b = cq_bufs(m, n, ws);
   hipError_t e;
   if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
-  if ((e = cq_pass(m, n, b.npad, A, lda, b.Qa, m, b.R1, b.Rinv, b.T, true, false, d_flag, s)) != hipSuccess) return e;
+  if ((e = cq_pass(m, n, b.npad, A, lda, b.Qa, m, b.R1, b.Rinv, b.T, true, false, d_flag, s, shift_scale)) != hipSuccess) return e;
   if ((e = cq_pass(m, n, b.npad, b.Qa, m, b.Qb, m, b.R2, b.Rinv, b.T, false, false, d_flag, s)) != hipSuccess) return e;
   if ((e = cq_pass_firstorder(m, n, b.npad, b.Qb, m, Q, ldq, b.R3, b.Rinv, b.T, d_flag, s)) != hipSuccess) return e;
   return cq_finish(b, n, R, ldr, d_flag, flag_out, s);
@@ -639,8 +645,8 @@ hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int 
 }
 
 hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
-                   int* d_flag, int* flag_out, hipStream_t s) {
-  hipError_t e = cholqr3_enqueue(m, n, A, lda, Q, ldq, R, ldr, ws, d_flag, flag_out, s);
+                   int* d_flag, int* flag_out, hipStream_t s, double shift_scale) {
+  hipError_t e = cholqr3_enqueue(m, n, A, lda, Q, ldq, R, ldr, ws, d_flag, flag_out, s, shift_scale);
   if (e != hipSuccess) return e;
   return cholqr3_finalize(m, n, Q, ldq, R, ldr, ws, d_flag, flag_out, s);
 }

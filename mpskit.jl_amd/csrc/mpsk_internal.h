@@ -138,11 +138,11 @@ hipError_t qrpos(int m, int n, const double* A, int lda, double* Q, int ldq, dou
 
 size_t cholqr_workspace_doubles(int m, int n);
 hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
-                   int* d_flag, int* flag_out, hipStream_t s);
+                   int* d_flag, int* flag_out, hipStream_t s, double shift_scale = 1.0);
 hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                          int* d_flag, int* flag_out, hipStream_t s);
 hipError_t cholqr3_enqueue(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
-                           int* d_flag, int* flag_out, hipStream_t s);
+                           int* d_flag, int* flag_out, hipStream_t s, double shift_scale = 1.0);
 hipError_t cholqr3_finalize(int m, int n, double* Q, int ldq, double* R, int ldr, double* ws, int* d_flag,
                             int* flag_out, hipStream_t s);
 size_t tsvd_workspace_bytes(int m, int n);

@@ -597,3 +597,23 @@ def test_deferred_gauge_completion(be):
     be.gemm(Q1, R1)
     be.qr_commit()
     assert relerr(be.download(L), La) < 1e-12 and relerr(be.download(Ql), Qla) < 1e-12
+
+
+def test_cholqr_shift_retry(be):
+    """The first CholeskyQR3 attempt uses a shift at the rounding level of the Gram matrix; on a matrix whose Gram matrix is
+    numerically indefinite (cond 1e12) the device flags the breakdown and the factorization is repeated with the shift of
+    Fukaya et al. -- same QRpos factors as Householder, counted by mpsk_ctx_qr_retries; a benign matrix needs no repeat."""
+    rng = np.random.default_rng(8)
+    m, n = 640, 192
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    r0 = be.qr_retries()
+    Q, R = (be.download(t) for t in be.qrpos(be.upload(rng.standard_normal((m, n)))))
+    assert be.qr_retries() == r0
+    A = (U * np.logspace(0, -12, n)) @ V.T
+    Q, R = (be.download(t) for t in be.qrpos(be.upload(A)))
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-13
+    assert np.abs(Q @ R - A).max() < 1e-14
+    assert np.all(np.diag(R) > 0) and np.abs(np.tril(R, -1)).max() == 0.0
+    s = be.qr_stats()
+    assert be.qr_retries() > r0 or s["fallback"] > 0        # the rounding-level shift cannot have been enough here
