@@ -131,20 +131,143 @@ __device__ __forceinline__ void cq_prod(cq_d4 (&acc)[2][2], const double* __rest
   }
 }
 
+// ---- in-place triangular solve B <- B R^-1 riding on the step launches (trsm != 0) ------------------------------------
+// Q = X R^-1 used to cost the recursive-doubling inverse (12 dependent small-GEMM launches) plus one GEMM AFTER the
+// latency-bound factorization chain, during which the chip is mostly idle.  The right-looking block substitution
+//   Q_c = (B_c - sum_{l<c} Q_l R_lc) Rinv_cc
+// is executed instead by extra workgroups of the step launches themselves, two launches behind the factorization:
+//   launch k:  Qt(c = k-2):  Q_c  = (B_c - Q_{c-1} R_{c-1,c}) Rinv_cc      (the last pending update folded in)
+//              Ut(l = k-3):  B_j -= Q_l R_lj  for j >= l + 2
+// (R row c is written by the panel tiles of launch c+1, Rinv_cc by the diagonal workgroup of launch c; every tile is one
+// or two 64^3 products, shorter than the diagonal workgroup's path, so the chain is not lengthened), and the solve is
+// finished two launches after the factorization.  B (m x n, ld ldb) holds a copy of X on entry and Q on exit.
+__device__ __forceinline__ void cq_fetch_tile_g(cq_d2 (&r)[8], const double* __restrict__ src, int ld, int row0, int col0,
+                                                int m, int n, int tid) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int v = tid + 256 * q, r2 = (v & 31) * 2, c = v >> 5;
+    const int gr = row0 + r2, gc = col0 + c;
+    cq_d2 t = {0.0, 0.0};
+    if (gc < n) {
+      const double* p = src + gr + (int64_t)gc * ld;
+      if (gr < m) t.x = p[0];
+      if (gr + 1 < m) t.y = p[1];
+    }
+    r[q] = t;
+  }
+}
+__device__ __forceinline__ void cq_put_tile_T(double* __restrict__ dst, const cq_d2 (&r)[8], int tid) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {                 // element (r2, c) -> position r2 * SL + c: cq_prod then contracts the COLUMN index
+    const int v = tid + 256 * q, r2 = (v & 31) * 2, c = v >> 5;
+    dst[r2 * CQ_SL + c] = r[q].x;
+    dst[(r2 + 1) * CQ_SL + c] = r[q].y;
+  }
+}
+
 __global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, double* __restrict__ R,
                                                       double* __restrict__ Rinv, int npad, int k,
-                                                      int* __restrict__ flag) {
+                                                      int* __restrict__ flag, double* __restrict__ B, int m, int n,
+                                                      int ldb, int trsm) {
   extern __shared__ __attribute__((aligned(16))) double cq_sm[];
   double* sM = cq_sm;                      // R_{k-1,k-1}^-1
   double* sJ = cq_sm + CB * CQ_SL;         // G_{k-1, j}
   double* sI = cq_sm + 2 * CB * CQ_SL;     // G_{k-1, i}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, fq = lane >> 4, fr = lane & 15;
-  const int nb = npad / CB, kk = k - 1, nt = nb - k;
+  const int nb = npad / CB, kk = k - 1, nt = (nb - k > 0) ? nb - k : 0;
   const int ntrail = (k == 0) ? 1 : nt * (nt + 1) / 2;
   const int b = blockIdx.x;
   cq_d4 acc[2][2];
-  if (k >= 2 && (k & 1) == 0 && b == ntrail + nt) {
+  if (trsm && b >= ntrail + nt) {
+    const int mt = (m + CB - 1) / CB;
+    int t = b - ntrail - nt;
+    const int cQ = k - 2;                                    // column block solved in this launch
+    const bool hasQ = (cQ >= 0 && cQ < nb);
+    if (hasQ && t < mt) {
+      // ---- Qt: Q_c = (B_c - Q_{c-1} R_{c-1,c}) Rinv_cc on row tile t
+      const int row0 = t * CB, col0 = cQ * CB;
+      cq_d2 t0[8], t1[8], t2[8];
+      cq_fetch_tile(t2, Rinv + (int64_t)cQ * CB * (npad + 1), npad, tid);
+      if (cQ > 0) {
+        cq_fetch_tile_g(t0, B, ldb, row0, col0 - CB, m, n, tid);                              // Q_{c-1}[rows]
+        cq_fetch_tile(t1, R + (int64_t)(cQ - 1) * CB + (int64_t)cQ * CB * npad, npad, tid);   // R_{c-1,c}
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int gr = row0 + 32 * wr + 16 * ti + fq + 4 * rg, gc = col0 + 32 * wc + 16 * tj + fr;
+            acc[ti][tj][rg] = (gr < m && gc < n) ? B[gr + (int64_t)gc * ldb] : 0.0;
+          }
+      if (cQ > 0) {
+        cq_put_tile_T(sM, t0, tid);
+        cq_put_tile(sJ, t1, tid);
+        __syncthreads();
+        cq_prod(acc, sM, sJ, -1.0, wr, wc, fr, fq);          // B_c - Q_{c-1} R_{c-1,c}
+        __syncthreads();
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)                     // sI <- P^T
+            sI[(32 * wr + 16 * ti + fq + 4 * rg) * CQ_SL + 32 * wc + 16 * tj + fr] = acc[ti][tj][rg];
+      cq_put_tile(sJ, t2, tid);
+      __syncthreads();
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0};
+      cq_prod(acc, sI, sJ, 1.0, wr, wc, fr, fq);             // P Rinv_cc
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int gr = row0 + 32 * wr + 16 * ti + fq + 4 * rg, gc = col0 + 32 * wc + 16 * tj + fr;
+            if (gr < m && gc < n) B[gr + (int64_t)gc * ldb] = acc[ti][tj][rg];
+          }
+      return;
+    }
+    if (hasQ) t -= mt;
+    // ---- Ut: B_j -= Q_l R_lj for l = k - 3, j = l + 2 + t / mt, row tile t % mt
+    const int l = k - 3;
+    const int j = l + 2 + t / mt, rt = t % mt;
+    if (l < 0 || j >= nb) return;
+    const int row0 = rt * CB, col0 = j * CB;
+    cq_d2 t0[8], t1[8];
+    cq_fetch_tile_g(t0, B, ldb, row0, l * CB, m, n, tid);                                      // Q_l[rows]
+    cq_fetch_tile(t1, R + (int64_t)l * CB + (int64_t)j * CB * npad, npad, tid);               // R_lj
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int gr = row0 + 32 * wr + 16 * ti + fq + 4 * rg, gc = col0 + 32 * wc + 16 * tj + fr;
+          acc[ti][tj][rg] = (gr < m && gc < n) ? B[gr + (int64_t)gc * ldb] : 0.0;
+        }
+    cq_put_tile_T(sM, t0, tid);
+    cq_put_tile(sJ, t1, tid);
+    __syncthreads();
+    cq_prod(acc, sM, sJ, -1.0, wr, wc, fr, fq);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int gr = row0 + 32 * wr + 16 * ti + fq + 4 * rg, gc = col0 + 32 * wc + 16 * tj + fr;
+          if (gr < m && gc < n) B[gr + (int64_t)gc * ldb] = acc[ti][tj][rg];
+        }
+    return;
+  }
+  if (!trsm && k >= 2 && (k & 1) == 0 && b == ntrail + nt) {
     // ---- first level of the inverse, off the critical path: the pair of diagonal blocks (a, a+1) = (k-2, k-1) is
     // complete (R_{a,a+1} from the panel tiles and R_{a+1,a+1}^-1 from the diagonal workgroup of launch k-1), so
     //   Rinv_{a,a+1} = - Rinv_aa R_{a,a+1} Rinv_{a+1,a+1}
@@ -420,11 +543,36 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
   const int nb = npad / CB;
   static std::atomic<uint64_t> step_attr{0};
   if ((e = ensure_dyn_smem(step_attr, reinterpret_cast<const void*>(cq_step_kernel), CQ_STEP_LDS)) != hipSuccess) return e;
+  // (worth it while one launch's substitution tiles fit about two waves of workgroups: 2048 x 1024 1.59 -> 1.32 ms,
+  //  1100 x 700 1.39 -> 1.13 ms; at 4096^2 there are 4096 tiles per launch, the chain is lengthened and the GEMM path
+  //  below is faster, 23.8 vs 24.8 ms)
+  static const bool trsm_enabled = !(getenv("MPSK_CQ_TRSM") && atoi(getenv("MPSK_CQ_TRSM")) == 0);
+  const bool use_trsm = trsm_enabled && (int64_t)nb * ((m + CB - 1) / CB) <= 1024;
+  if (use_trsm) {
+    // Q = X R^-1 by the in-step block substitution (see cq_step_kernel): Q starts as a copy of X and is solved in place,
+    // two launches behind the factorization; no explicit inverse, no separate GEMM
+    if (X != Q) {
+      if ((e = hipMemcpy2DAsync(Q, sizeof(double) * (size_t)ldq, X, sizeof(double) * (size_t)ldx, sizeof(double) * (size_t)m, n,
+                                hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+    }
+    const int mt = (m + CB - 1) / CB;
+    for (int k = 0; k <= nb + 1; ++k) {
+      const int nt = (nb - k > 0) ? nb - k : 0;
+      int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt;
+      if (k - 2 >= 0 && k - 2 < nb) nwg += mt;                               // Qt(k - 2)
+      if (k - 3 >= 0 && nb - k + 1 > 0) nwg += (nb - k + 1) * mt;            // Ut(k - 3): columns k - 1 .. nb - 1
+      if (nwg > 0)
+        hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag, Q, m, n, ldq, 1);
+    }
+    hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
+    return hipGetLastError();
+  }
   for (int k = 0; k <= nb; ++k) {           // one fused launch per block column (see cq_step_kernel); even launches
     const int nt = nb - k;                  // k >= 2 carry one more workgroup (pair inverse), k == nb is that one alone
     const int pairwg = (k >= 2 && (k & 1) == 0) ? 1 : 0;
     const int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt + pairwg;
-    if (nwg > 0) hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag);
+    if (nwg > 0)
+      hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag, (double*)nullptr, 0, 0, 0, 0);
   }
   hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
   // R^{-1} by recursive doubling: inv([R11 R12; 0 R22]) = [i11, -i11 R12 i22; 0, i22]
