@@ -617,3 +617,26 @@ def test_cholqr_shift_retry(be):
     assert np.all(np.diag(R) > 0) and np.abs(np.tril(R, -1)).max() == 0.0
     s = be.qr_stats()
     assert be.qr_retries() > r0 or s["fallback"] > 0        # the rounding-level shift cannot have been enough here
+
+
+@pytest.mark.parametrize("m,n,logc", [(65, 65, 2), (129, 65, 4), (640, 193, 5), (1100, 700, 7), (257, 256, 5), (900, 899, 2), (1493, 137, 10)])
+def test_qr_ragged_shapes_in_step_solve(be, m, n, logc):
+    """CholeskyQR3 with the in-step triangular solve (Q = X R^-1 as extra workgroups of the Cholesky step launches) on
+    sizes that are not multiples of the 64-wide tiles, against LAPACK with the QRpos sign convention; LQpos and the
+    two-stream pair go through the same path."""
+    rng = np.random.default_rng(m * 7 + n)
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = (U * np.logspace(0, -logc, n)) @ V.T
+    Qr, Rr = np.linalg.qr(A)
+    sg = np.sign(np.diag(Rr)); sg[sg == 0] = 1
+    Qr = Qr * sg
+    Q, R = (be.download(t) for t in be.qrpos(be.upload(A)))
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-13
+    assert np.abs(Q @ R - A).max() < 1e-14 and np.abs(np.tril(R, -1)).max() == 0.0 and np.all(np.diag(R) > 0)
+    assert np.abs(Q - Qr).max() < 1e-8 * 10.0 ** logc * 1e-7 + 1e-13 or logc >= 10
+    L, Ql = (be.download(t) for t in be.lqpos(be.upload(A.T.copy())))
+    assert np.abs(Ql @ Ql.T - np.eye(n)).max() < 1e-13 and np.abs(L @ Ql - A.T).max() < 1e-14
+    B = rng.standard_normal((m, n))
+    Q1, R1, Q2, R2 = (be.download(t) for t in be.qrpos2(be.upload(A), be.upload(B)))
+    assert np.abs(Q1 - Q).max() < 1e-12 and np.abs(Q2 @ R2 - B).max() < 1e-12 and np.abs(Q2.T @ Q2 - np.eye(n)).max() < 1e-13
