@@ -131,6 +131,21 @@ __device__ __forceinline__ void cq_prod(cq_d4 (&acc)[2][2], const double* __rest
   }
 }
 
+constexpr int CQ_GS = 8;   // K-splits of the in-step Gram tiles (each workgroup: <= ceil(m / 64 / 8) products of 64^3)
+
+// G (upper block triangle) = sum of the CQ_GS partial Gram matrices the step launches left in Gp, in fixed order
+__global__ __launch_bounds__(256) void cq_gram_reduce_kernel(const double* __restrict__ Gp, int npad, double* __restrict__ G) {
+  const int64_t np2 = (int64_t)npad * npad;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < np2; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e % npad), c = (int)(e / npad);
+    if (r / CB > c / CB) continue;
+    double acc = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < CQ_GS; ++sp) acc += Gp[(int64_t)sp * np2 + e];
+    G[e] = acc;
+  }
+}
+
 // ---- in-place triangular solve B <- B R^-1 riding on the step launches (trsm != 0) ------------------------------------
 // Q = X R^-1 used to cost the recursive-doubling inverse (12 dependent small-GEMM launches) plus one GEMM AFTER the
 // latency-bound factorization chain, during which the chip is mostly idle.  The right-looking block substitution
@@ -141,6 +156,8 @@ __device__ __forceinline__ void cq_prod(cq_d4 (&acc)[2][2], const double* __rest
 // (R row c is written by the panel tiles of launch c+1, Rinv_cc by the diagonal workgroup of launch c; every tile is one
 // or two 64^3 products, shorter than the diagonal workgroup's path, so the chain is not lengthened), and the solve is
 // finished two launches after the factorization.  B (m x n, ld ldb) holds a copy of X on entry and Q on exit.
+// The same launches can also form the NEXT pass's Gram matrix Q^T Q (Gt tiles, column block j in launch j + 3, K split over
+// CQ_GS workgroups per tile): the 88 us Gram GEMM between two passes then shrinks to one more launch and a reduction.
 __device__ __forceinline__ void cq_fetch_tile_g(cq_d2 (&r)[8], const double* __restrict__ src, int ld, int row0, int col0,
                                                 int m, int n, int tid) {
 #pragma unroll
@@ -168,7 +185,7 @@ __device__ __forceinline__ void cq_put_tile_T(double* __restrict__ dst, const cq
 __global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, double* __restrict__ R,
                                                       double* __restrict__ Rinv, int npad, int k,
                                                       int* __restrict__ flag, double* __restrict__ B, int m, int n,
-                                                      int ldb, int trsm) {
+                                                      int ldb, int trsm, double* __restrict__ Gp) {
   extern __shared__ __attribute__((aligned(16))) double cq_sm[];
   double* sM = cq_sm;                      // R_{k-1,k-1}^-1
   double* sJ = cq_sm + CB * CQ_SL;         // G_{k-1, j}
@@ -235,6 +252,45 @@ __global__ __launch_bounds__(256) void cq_step_kernel(double* __restrict__ G, do
       return;
     }
     if (hasQ) t -= mt;
+    const int nU = (k - 3 >= 0 && nb - k + 1 > 0) ? (nb - k + 1) * mt : 0;
+    if (t >= nU) {
+      // ---- Gt: the NEXT pass's Gram matrix, column block j = k - 3 (Q_j is final since launch j + 2): tile (i, j), i <= j,
+      // over the row tiles of K-split sp -> partial tile sp (summed in fixed order by cq_gram_reduce_kernel)
+      t -= nU;
+      const int j = k - 3, i = t / CQ_GS, sp = t % CQ_GS;
+      if (Gp == nullptr || j < 0 || j >= nb || i > j) return;
+      const int chunk = (mt + CQ_GS - 1) / CQ_GS;
+      const int r0 = sp * chunk, r1 = (r0 + chunk < mt) ? r0 + chunk : mt;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = cq_d4{0.0, 0.0, 0.0, 0.0};
+      cq_d2 t0[8], t1[8];
+      if (r0 < r1) {
+        cq_fetch_tile_g(t0, B, ldb, r0 * CB, i * CB, m, n, tid);
+        if (i != j) cq_fetch_tile_g(t1, B, ldb, r0 * CB, j * CB, m, n, tid);
+      }
+      for (int rt = r0; rt < r1; ++rt) {
+        __syncthreads();                                     // the previous product has finished reading sM / sJ
+        cq_put_tile(sM, t0, tid);
+        if (i != j) cq_put_tile(sJ, t1, tid); else cq_put_tile(sJ, t0, tid);
+        __syncthreads();
+        if (rt + 1 < r1) {                                   // next row tile's loads fly while the MFMAs run
+          cq_fetch_tile_g(t0, B, ldb, (rt + 1) * CB, i * CB, m, n, tid);
+          if (i != j) cq_fetch_tile_g(t1, B, ldb, (rt + 1) * CB, j * CB, m, n, tid);
+        }
+        cq_prod(acc, sM, sJ, 1.0, wr, wc, fr, fq);           // += Q_i[rt]^T Q_j[rt]
+      }
+      double* Gt = Gp + (int64_t)sp * npad * npad + (int64_t)i * CB + (int64_t)j * CB * npad;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            Gt[(32 * wr + 16 * ti + fq + 4 * rg) + (int64_t)(32 * wc + 16 * tj + fr) * npad] = acc[ti][tj][rg];
+      return;
+    }
     // ---- Ut: B_j -= Q_l R_lj for l = k - 3, j = l + 2 + t / mt, row tile t % mt
     const int l = k - 3;
     const int j = l + 2 + t / mt, rt = t % mt;
@@ -508,11 +564,23 @@ __global__ __launch_bounds__(256) void cq_check_identity_kernel(const double* __
   if (bad) atomicOr(flag, 2);
 }
 
+// in-step triangular solve (and in-step Gram of the next pass): worth it while one launch's tiles fit about two waves of
+// workgroups: 2048 x 1024 1.59 -> 1.32 ms, 1100 x 700 1.39 -> 1.13 ms; at 4096^2 there are 4096 solve tiles per launch, the
+// chain is lengthened and the GEMM path is faster (23.8 vs 24.8 ms)
+static bool cq_use_trsm(int m, int npad) {
+  static const bool enabled = !(getenv("MPSK_CQ_TRSM") && atoi(getenv("MPSK_CQ_TRSM")) == 0);
+  return enabled && (int64_t)(npad / CB) * ((m + CB - 1) / CB) <= 1024;
+}
+static bool cq_use_gram(int m, int npad) {
+  static const bool enabled = !(getenv("MPSK_CQ_GRAM") && atoi(getenv("MPSK_CQ_GRAM")) == 0);
+  return enabled && cq_use_trsm(m, npad);
+}
+
 size_t cholqr_workspace_doubles(int m, int n) {
   int nb = (n + CB - 1) / CB, p2 = 1;
   while (p2 < nb) p2 <<= 1;
   size_t npad = (size_t)p2 * CB;
-  return 5 * npad * npad + 2 * (size_t)m * n + 16;
+  return 5 * npad * npad + 2 * (size_t)m * n + 16 + (cq_use_gram(m, (int)npad) ? (size_t)CQ_GS * npad * npad : 0);
 }
 
 static GemmArgs cq_mk(const double* A, const double* B, double* C, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -525,14 +593,17 @@ static GemmArgs cq_mk(const double* A, const double* B, double* C, int M, int N,
 }
 
 // One CholeskyQR pass.  X: m x n (ldx).  Writes Q (m x n, ldq) and the npad x npad upper factor Rp.
+// gram_ready: T already holds the Gram matrix of X (left there by the previous pass's step launches);
+// Gp_next (CQ_GS x npad x npad doubles, or null): this pass's step launches also form the partial Gram matrices of Q, and
+// their sum is left in T for the next pass.
 static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, double* Q, int ldq, double* Rp,
                           double* Rinv, double* T, bool shifted, bool check_identity, int* flag, hipStream_t s,
-                          double shift_scale = 1.0) {
+                          double shift_scale = 1.0, bool gram_ready = false, double* Gp_next = nullptr) {
   hipError_t e;
   double* Gw = T;                                                            // Gram matrix, consumed by the factorization
   GemmArgs g = cq_mk(X, X, Gw, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X: only the upper block triangle
   g.upper_only = 1;                                                          // is read by the factorization below
-  if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+  if (!gram_ready && (e = gemm_f64(g, s)) != hipSuccess) return e;
   if (npad > n) hipLaunchKernelGGL(cq_pad_identity_kernel, dim3(512), dim3(256), 0, s, Gw, npad, n);
   if (check_identity) hipLaunchKernelGGL(cq_check_identity_kernel, dim3(256), dim3(256), 0, s, Gw, npad, n, 0.5, flag);
   if (shifted) {
@@ -543,11 +614,7 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
   const int nb = npad / CB;
   static std::atomic<uint64_t> step_attr{0};
   if ((e = ensure_dyn_smem(step_attr, reinterpret_cast<const void*>(cq_step_kernel), CQ_STEP_LDS)) != hipSuccess) return e;
-  // (worth it while one launch's substitution tiles fit about two waves of workgroups: 2048 x 1024 1.59 -> 1.32 ms,
-  //  1100 x 700 1.39 -> 1.13 ms; at 4096^2 there are 4096 tiles per launch, the chain is lengthened and the GEMM path
-  //  below is faster, 23.8 vs 24.8 ms)
-  static const bool trsm_enabled = !(getenv("MPSK_CQ_TRSM") && atoi(getenv("MPSK_CQ_TRSM")) == 0);
-  const bool use_trsm = trsm_enabled && (int64_t)nb * ((m + CB - 1) / CB) <= 1024;
+  const bool use_trsm = cq_use_trsm(m, npad);
   if (use_trsm) {
     // Q = X R^-1 by the in-step block substitution (see cq_step_kernel): Q starts as a copy of X and is solved in place,
     // two launches behind the factorization; no explicit inverse, no separate GEMM
@@ -556,15 +623,18 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
                                 hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
     }
     const int mt = (m + CB - 1) / CB;
-    for (int k = 0; k <= nb + 1; ++k) {
+    for (int k = 0; k <= nb + (Gp_next ? 2 : 1); ++k) {
       const int nt = (nb - k > 0) ? nb - k : 0;
       int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt;
       if (k - 2 >= 0 && k - 2 < nb) nwg += mt;                               // Qt(k - 2)
       if (k - 3 >= 0 && nb - k + 1 > 0) nwg += (nb - k + 1) * mt;            // Ut(k - 3): columns k - 1 .. nb - 1
+      if (Gp_next && k - 3 >= 0 && k - 3 < nb) nwg += (k - 2) * CQ_GS;       // Gt(k - 3): tiles (0 .. k-3, k-3) x K-splits
       if (nwg > 0)
-        hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag, Q, m, n, ldq, 1);
+        hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag, Q, m, n, ldq, 1,
+                           Gp_next);
     }
     hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
+    if (Gp_next) hipLaunchKernelGGL(cq_gram_reduce_kernel, dim3(1024), dim3(256), 0, s, Gp_next, npad, T);   // T is free again
     return hipGetLastError();
   }
   for (int k = 0; k <= nb; ++k) {           // one fused launch per block column (see cq_step_kernel); even launches
@@ -572,7 +642,8 @@ static hipError_t cq_pass(int m, int n, int npad, const double* X, int ldx, doub
     const int pairwg = (k >= 2 && (k & 1) == 0) ? 1 : 0;
     const int nwg = (k == 0) ? 1 : nt * (nt + 1) / 2 + nt + pairwg;
     if (nwg > 0)
-      hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag, (double*)nullptr, 0, 0, 0, 0);
+      hipLaunchKernelGGL(cq_step_kernel, dim3(nwg), dim3(256), CQ_STEP_LDS, s, Gw, Rp, Rinv, npad, k, flag, (double*)nullptr, 0, 0, 0, 0,
+                         (double*)nullptr);
   }
   hipLaunchKernelGGL(cq_cleanup_kernel, dim3(1024), dim3(256), 0, s, Rp, Rinv, npad);
   // R^{-1} by recursive doubling: inv([R11 R12; 0 R22]) = [i11, -i11 R12 i22; 0, i22]
@@ -632,11 +703,11 @@ __global__ __launch_bounds__(256) void cq_firstorder_kernel(const double* __rest
 }
 
 static hipError_t cq_pass_firstorder(int m, int n, int npad, const double* X, int ldx, double* Q, int ldq, double* Rp,
-                                     double* Rinv, double* T, int* flag, hipStream_t s) {
+                                     double* Rinv, double* T, int* flag, hipStream_t s, bool gram_ready = false) {
   hipError_t e;
   GemmArgs g = cq_mk(X, X, T, n, n, m, ldx, ldx, npad, 1, 1.0, 0.0);      // G = X^T X  (into T), upper block triangle
   g.upper_only = 1;
-  if ((e = gemm_f64(g, s)) != hipSuccess) return e;
+  if (!gram_ready && (e = gemm_f64(g, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(cq_firstorder_kernel, dim3(1024), dim3(256), 0, s, T, npad, n, Rp, Rinv, flag, CQ_FIRSTORDER_MAX);
   g = cq_mk(X, Rinv, Q, m, n, n, ldx, npad, ldq, 0, 1.0, 0.0);
   g.b_upper = 1;                                                           // Minv = I - U is upper triangular
@@ -647,7 +718,7 @@ static hipError_t cq_pass_firstorder(int m, int n, int npad, const double* X, in
 //   cholqr3_enqueue  : launches everything (passes 1, 2, first-order pass 3, R product, flag copy) -- no sync
 //   cholqr3_finalize : syncs the stream, repeats pass 3 with the full Cholesky if the device asked for it.
 // *flag_out != 0 after finalize means "not trustworthy, fall back to Householder".
-struct CqBufs { double *R1, *R2, *R3, *Rinv, *T, *Qa, *Qb; int npad; };
+struct CqBufs { double *R1, *R2, *R3, *Rinv, *T, *Qa, *Qb, *Gp; int npad; };
 static CqBufs cq_bufs(int m, int n, double* ws) {
   int nb = (n + CB - 1) / CB, p2 = 1;
   while (p2 < nb) p2 <<= 1;
@@ -656,6 +727,7 @@ static CqBufs cq_bufs(int m, int n, double* ws) {
   const size_t np2 = (size_t)b.npad * b.npad;
   b.R1 = ws; b.R2 = b.R1 + np2; b.R3 = b.R2 + np2; b.Rinv = b.R3 + np2; b.T = b.Rinv + np2;
   b.Qa = b.T + np2; b.Qb = b.Qa + (size_t)m * n;
+  b.Gp = cq_use_gram(m, b.npad) ? b.Qb + (((size_t)m * n + 1) & ~(size_t)1) : nullptr;   // CQ_GS partial Gram matrices
   return b;
 }
 static hipError_t cq_finish(const CqBufs& b, int n, double* R, int ldr, int* d_flag, int* flag_out, hipStream_t s) {
@@ -682,9 +754,11 @@ hipError_t cholqr3_enqueue(int m, int n, const double* A, int lda, double* Q, in
   const CqBufs b = cq_bufs(m, n, ws);
   hipError_t e;
   if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
-  if ((e = cq_pass(m, n, b.npad, A, lda, b.Qa, m, b.R1, b.Rinv, b.T, true, false, d_flag, s, shift_scale)) != hipSuccess) return e;
-  if ((e = cq_pass(m, n, b.npad, b.Qa, m, b.Qb, m, b.R2, b.Rinv, b.T, false, false, d_flag, s)) != hipSuccess) return e;
-  if ((e = cq_pass_firstorder(m, n, b.npad, b.Qb, m, Q, ldq, b.R3, b.Rinv, b.T, d_flag, s)) != hipSuccess) return e;
+  // (with the in-step Gram, every pass leaves the Gram matrix of its Q in T for the next one)
+  const bool gr = (b.Gp != nullptr);
+  if ((e = cq_pass(m, n, b.npad, A, lda, b.Qa, m, b.R1, b.Rinv, b.T, true, false, d_flag, s, shift_scale, false, b.Gp)) != hipSuccess) return e;
+  if ((e = cq_pass(m, n, b.npad, b.Qa, m, b.Qb, m, b.R2, b.Rinv, b.T, false, false, d_flag, s, 1.0, gr, b.Gp)) != hipSuccess) return e;
+  if ((e = cq_pass_firstorder(m, n, b.npad, b.Qb, m, Q, ldq, b.R3, b.Rinv, b.T, d_flag, s, gr)) != hipSuccess) return e;
   return cq_finish(b, n, R, ldr, d_flag, flag_out, s);
 }
 
