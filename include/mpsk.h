@@ -138,6 +138,13 @@ typedef struct mpsk_hac mpsk_hac;
 int mpsk_hac_create(mpsk_ctx* ctx, const mpsk_mposlice* H, int Dlo, int Dl, int Dr, const void* GL, const void* GR,
                     mpsk_hac** out);
 int mpsk_hac_apply(mpsk_hac* h, const void* x, int nblk, void* y);
+/* Fixed-budget smallest-real eigensolve with the prepared operator in ONE call: V[0] = x0 / |x0|, m Krylov steps (apply,
+ * CGS2 + normalise), Ritz step of the projected matrix on the device, y = normalised Ritz vector -- fixedpoint(H_AC, AC, :SR,
+ * Arnoldi(; krylovdim = m, maxiter = 1)) of dmrg.jl:36 without a convergence test and without a host synchronisation.
+ * V: HOST array of m + 2 device vectors of the operator's size; scal: device scratch, >= m (2m + 1) + 40 doubles;
+ * first_image (optional): H (x0 / |x0|) as the first step produced it (what calc_galerkin of the old tensor needs,
+ * toolbox.jl:18).  1 <= m <= 32, MPSK_F64 operators, unblocked vectors. */
+int mpsk_hac_eigsolve_fixed(mpsk_hac* hac, const void* x0, int m, void* const* V, void* scal, void* y, void* first_image);
 int mpsk_hac_destroy(mpsk_hac* h);
 int mpsk_hac_info(const mpsk_hac* h, int* mode, int* nslabs);
 /* mpsk_dC == dC(x, leftenv::Vector, rightenv::Vector)   derivatives.jl:171-193

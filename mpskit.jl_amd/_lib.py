@@ -101,6 +101,7 @@ SIGNATURES = {
     "mpsk_ctx_side_begin": [C.c_void_p],
     "mpsk_ctx_side_end": [C.c_void_p],
     "mpsk_qr_commit": [C.c_void_p, C.POINTER(C.c_int)],
+    "mpsk_hac_eigsolve_fixed": [C.c_void_p, C.c_void_p, C.c_int, c_void_pp, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vritz_dev": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vlincomb_dev": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, C.c_void_p],
 }

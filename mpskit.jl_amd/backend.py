@@ -574,6 +574,14 @@ class PreparedHAC:
         check(self.be.lib.mpsk_hac_apply(self.handle, x.ptr, int(nblk), y.ptr), "mpsk_hac_apply")
         return y
 
+    def eigsolve_fixed(self, x0: DTensor, m: int, vecs, scal: DTensor, out: DTensor, first_image: DTensor = None):
+        """mpsk_hac_eigsolve_fixed: the whole fixed-budget solve (m steps) in one call; vecs = m + 2 work vectors."""
+        assert not self.cplx and len(vecs) >= m + 2 and scal.size >= m * (2 * m + 1) + 40
+        ptrs = self.be._ptrs(vecs[:m + 2])
+        check(self.be.lib.mpsk_hac_eigsolve_fixed(self.handle, x0.ptr, int(m), ptrs, scal.ptr, out.ptr,
+                                                  None if first_image is None else first_image.ptr), "mpsk_hac_eigsolve_fixed")
+        return out
+
     def close(self):
         if getattr(self, "handle", None) and self.be.ctx:
             self.be.lib.mpsk_hac_destroy(self.handle)

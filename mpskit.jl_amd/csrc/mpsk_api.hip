@@ -800,6 +800,37 @@ int mpsk_hac_apply(mpsk_hac* h, const void* x, int nblk, void* y) {
   return MPSK_OK;
 }
 
+// Fixed-budget smallest-real solve with the prepared operator, one call per site (fixedpoint(H_AC, AC, :SR, alg) of
+// dmrg.jl:36 with Arnoldi(; krylovdim = m, maxiter = 1) and no convergence test): V[0] = x0 / |x0|, m Krylov steps
+// (apply, CGS2 + normalise), Ritz step of the m x m projected matrix on the device, y = normalised Ritz vector.  Nothing is
+// read back; the ~30 entry-point calls the host made per site become one (at D = 256 the host could not keep the stream fed).
+// V: HOST array of m + 2 device vectors of the operator's size (Krylov basis + assembly scratch); scal: device scratch of
+// >= m (2m + 1) + 40 doubles; first_image (optional): receives H (x0 / |x0|) before it is orthogonalised (calc_galerkin of the
+// old tensor needs exactly that vector, toolbox.jl:18).  MPSK_F64 operators, unblocked vector layout.
+int mpsk_hac_eigsolve_fixed(mpsk_hac* h, const void* x0, int m, void* const* V, void* scal, void* y, void* first_image) {
+  REQUIRE(h && x0 && V && scal && y, "NULL argument");
+  REQUIRE(m >= 1 && m <= 32, "needs 1 <= m <= 32");
+  REQUIRE(h->mode != 2, "mpsk_hac_eigsolve_fixed: MPSK_F64 operators only");
+  mpsk_ctx* c = h->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const int64_t n = (int64_t)h->Dlo * h->H->d * h->Dr;
+  REQUIRE(h->Dlo == h->Dl, "mpsk_hac_eigsolve_fixed: the operator must be square (unsharded)");
+  double* slot = (double*)scal;
+  const int stride = 2 * m + 1;
+  double* rbuf = slot + (size_t)m * stride;           // Ritz coefficients [0:32], info [32:35]
+  if (int rc = mpsk_vnormalize_dev(c, n, x0, V[0], nullptr)) return rc;
+  for (int k = 0; k < m; ++k) {
+    if (int rc = mpsk_hac_apply(h, V[k], 1, V[k + 1])) return rc;
+    if (k == 0 && first_image) HIPCHK(hipMemcpyAsync(first_image, V[1], sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(vec_cgs2((const double* const*)V, k + 1, (double*)V[k + 1], n, slot + (size_t)k * stride, c->d_partial, c->stream));
+    HIPCHK(vec_scal_rsqrt_dev(slot + (size_t)k * stride + 2 * (k + 1), (double*)V[k + 1], n, c->stream));
+  }
+  HIPCHK(vec_ritz_small(slot, m, stride, rbuf, rbuf + 32, c->stream));
+  HIPCHK(hipMemsetAsync(V[m + 1], 0, sizeof(double) * n, c->stream));
+  HIPCHK(vec_multiaxpy((const double* const*)V, rbuf, m, 1.0, (double*)V[m + 1], n, c->stream));
+  return mpsk_vnormalize_dev(c, n, V[m + 1], y, nullptr);
+}
+
 int mpsk_dC(mpsk_ctx* c, int W, int Dlo, int Dl, int Dr, const void* GL, const void* GR, const void* cm, void* y) {
   REQUIRE(c && GL && GR && cm && y, "NULL argument");
   REQUIRE(W > 0 && Dlo > 0 && Dl > 0 && Dr > 0, "dimensions must be positive");

@@ -34,6 +34,17 @@ class MPO_ddAC:  # MPO_∂∂AC  derivatives.jl:11-15
 
     __mul__ = __call__
 
+    def eigsolve_fixed(self, x0: DTensor, m: int, vecs, scal: DTensor, out: DTensor, first_image: DTensor = None):
+        """Fixed-budget :SR solve in one library call (mpsk_hac_eigsolve_fixed); None if this operator cannot take it
+        (host stand-in backend, complex operator)."""
+        if not hasattr(self.be, "hac_create"):
+            return None
+        if self._hac is None:
+            self._hac = self.be.hac_create(self.o, self.leftenv, self.rightenv)
+        if self._hac.cplx or self._hac.Dlo != self._hac.Dl:
+            return None
+        return self._hac.eigsolve_fixed(x0, m, vecs, scal, out, first_image)
+
 
 class MPO_ddAC2:  # MPO_∂∂AC2  derivatives.jl:17-22
     def __init__(self, be, o1, o2, leftenv, rightenv):

@@ -53,6 +53,13 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         # benchmark sweep have dimension 4 < 8)
         m = max(1, min(fixed_matvecs, x0.size))
         stride = 2 * m + 1
+        if not values and m <= 32 and hasattr(matvec, "eigsolve_fixed"):
+            # the whole solve as ONE library call (mpsk_hac_eigsolve_fixed): same kernels in the same order as below,
+            # without the ~30 entry-point calls per site the host otherwise makes (they starve the stream at small D)
+            out = be.empty(*shape)
+            scal = ws.get((m * stride + 40, 1), 1)[0]
+            if matvec.eigsolve_fixed(start, m, V[:m + 1] + [ritz], scal, out, first_image) is not None:
+                return None, out, fixed_matvecs, None
         slot = ws.get((m * stride,), 1)[0]
         be.normalize_dev(start, out=V[0])              # no host round trip: the solve has ONE synchronisation, below
         for k in range(m):

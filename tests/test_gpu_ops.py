@@ -640,3 +640,30 @@ def test_qr_ragged_shapes_in_step_solve(be, m, n, logc):
     B = rng.standard_normal((m, n))
     Q1, R1, Q2, R2 = (be.download(t) for t in be.qrpos2(be.upload(A), be.upload(B)))
     assert np.abs(Q1 - Q).max() < 1e-12 and np.abs(Q2 @ R2 - B).max() < 1e-12 and np.abs(Q2.T @ Q2 - np.eye(n)).max() < 1e-13
+
+
+def test_one_call_fixed_budget_eigsolve(be):
+    """mpsk_hac_eigsolve_fixed (the site's whole fixed-budget solve in one library call) against the step-by-step host
+    loop with the host Ritz step: same Ritz vector (positive overlap with the start), same captured first image."""
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import krylov
+    rng = np.random.default_rng(17)
+    D, d, W = 96, 2, 5
+    H = mk.heisenberg_XXX(0.5, be=be)
+    g = rng.standard_normal((W, D, D)); g = g + np.transpose(g, (0, 2, 1))
+    GL = be.upload_env([m_[:, None, :] for m_ in g])
+    GR = be.upload_env([m_[:, None, :] for m_ in g[::-1]])
+    x0 = be.upload(rng.standard_normal((D, d, D)))
+    for m in (1, 3, 8):
+        h1 = mk.MPO_ddAC(be, H[1], GL, GR)
+        f1 = be.empty(D, d, D)
+        none, v1, _, _ = krylov.eigsolve_sr(be, h1, x0, fixed_matvecs=m, krylovdim=m, values=False, first_image=f1)
+        assert none is None
+        h2 = mk.MPO_ddAC(be, H[1], GL, GR)
+        f2 = be.empty(D, d, D)
+        lam, v2, _, _ = krylov.eigsolve_sr(be, lambda x, out=None: h2(x, out=out), x0, fixed_matvecs=m, krylovdim=m, first_image=f2)
+        a, b = be.download(v1).ravel(), be.download(v2).ravel()
+        assert abs(np.linalg.norm(a) - 1.0) < 1e-13
+        assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-11, m
+        assert a @ be.download(x0).ravel() > 0
+        assert np.abs(be.download(f1) - be.download(f2)).max() < 1e-12 * np.abs(be.download(f2)).max()
