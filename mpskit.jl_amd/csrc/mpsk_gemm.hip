@@ -462,7 +462,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
   const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
   const int ntiles = tilesM * tilesN;
   int bid = blockIdx.x;
-  {
+  if (!g.xcd_interleave) {
     int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, pos = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   }
@@ -503,7 +503,7 @@ __device__ __forceinline__ void gemm_sk_body(const GemmArgs& g) {
   const int U = ntiles * g.batch * KT;
   // XCD-aware share order: workgroups b, b+8, ... share an L2 -> give each XCD a contiguous run of shares
   int sid = blockIdx.x;
-  {
+  if (!g.xcd_interleave) {
     const int nwg = gridDim.x;
     int q = nwg / 8, r = nwg % 8, xcd = sid % 8, pos = sid / 8;
     sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
@@ -930,12 +930,17 @@ hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {
       }
     }
   }
+  // triangular work (symmetric result / triangular operands): the k-range of a tile grows with its column (row) index, so
+  // contiguous per-XCD chunks -- rectangles or strips -- leave some XCDs with several times the work of others (Q = X R^-1
+  // with the upper-triangular operand: 5.6x between the first and the last column group); consecutive tiles then go to
+  // consecutive XCDs (the hardware's round-robin) instead
+  g.xcd_interleave = (g.upper_only || g.a_upper || g.b_upper) ? 1 : 0;
   {  // XCD grid: minimise the operand rows + columns an XCD's L2 has to stream, M/gx + N/gy
     const int tM = (g.M + bm - 1) / bm, tN = (g.N + bn - 1) / bn;
     g.xcd_gx = g.xcd_gy = 0;
     const bool chunks_ok = ((int64_t)tM * tN) % 8 == 0 &&
                            (g.sk_units == 0 || (((g.K + BK - 1) / BK) * g.nseg) % g.sk_units == 0);
-    if (chunks_ok && g_xcd_grid_enabled) {
+    if (chunks_ok && g_xcd_grid_enabled && !g.xcd_interleave) {
       double best = 0.0;
       const int cand[4][2] = {{1, 8}, {2, 4}, {4, 2}, {8, 1}};
       for (int c = 0; c < 4; ++c) {

@@ -51,6 +51,7 @@ struct GemmArgs {
   double* sk_ws;
   // XCD grid (set by gemm_f64): the 8 XCDs' tile chunks are xcd_gx x xcd_gy rectangles of the tile grid (0: linear)
   int xcd_gx, xcd_gy;
+  int xcd_interleave;   // triangular work (upper_only / a_upper / b_upper): tiles round-robin over the XCDs instead of chunks
   // optional per-batch K-segment offsets (device arrays [batch][nseg], element offsets): batch z reads segment i at
   // A + tabA/bsA offset + zsegA[z * nseg + i] (override segA / segB when set; nseg is uniform over the batches)
   const int64_t* zsegA;
