@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void cq_check_identity_kernel(const double* __
 // chain is lengthened and the GEMM path is faster (23.8 vs 24.8 ms)
 static bool cq_use_trsm(int m, int npad) {
   static const bool enabled = !(getenv("MPSK_CQ_TRSM") && atoi(getenv("MPSK_CQ_TRSM")) == 0);
-  return enabled && (int64_t)(npad / CB) * ((m + CB - 1) / CB) <= 1024;
+  return enabled && (int64_t)(npad / CB) * ((m + CB - 1) / CB) <= 768;     // 2048 x 1024: 512; 4096 x 1024 (1024): GEMM path 1.84 vs 1.97 ms
 }
 static bool cq_use_gram(int m, int npad) {
   static const bool enabled = !(getenv("MPSK_CQ_GRAM") && atoi(getenv("MPSK_CQ_GRAM")) == 0);
