@@ -131,7 +131,7 @@ __device__ __forceinline__ void cq_prod(cq_d4 (&acc)[2][2], const double* __rest
   }
 }
 
-constexpr int CQ_GS = 8;   // K-splits of the in-step Gram tiles (each workgroup: <= ceil(m / 64 / 8) products of 64^3)
+constexpr int CQ_GS = 16;  // K-splits of the in-step Gram tiles (each workgroup: <= ceil(m / 64 / 16) products of 64^3; 8: QRpos 1.28 ms, 16: 1.22 ms)
 
 // G (upper block triangle) = sum of the CQ_GS partial Gram matrices the step launches left in Gp, in fixed order
 __global__ __launch_bounds__(256) void cq_gram_reduce_kernel(const double* __restrict__ Gp, int npad, double* __restrict__ G) {
