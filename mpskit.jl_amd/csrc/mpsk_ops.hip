@@ -484,9 +484,15 @@ __global__ __launch_bounds__(64) void ritz_small_kernel(const double* __restrict
   const int ne = me + (me & 1);                         // even player count; index me (if odd) is a bye
   const int half = ne / 2;
   for (int sweep = 0; sweep < 24; ++sweep) {
+    // off-diagonal / diagonal weight: lane t sums row t, the wave adds the rows (the all-lanes-read-everything form cost
+    // 2 m^2 dependent LDS reads per sweep -- more than the seven rotation rounds of an m = 8 sweep)
     double off = 0.0, dia = 0.0;
-    for (int i = 0; i < me; ++i) for (int j = 0; j < me; ++j) { if (i != j) off += A[i][j] * A[i][j]; else dia += A[i][i] * A[i][i]; }
-    if (off <= 1e-30 * dia) break;                       // (uniform: every lane reads the same LDS values)
+    if (t < me) {
+      for (int j = 0; j < me; ++j) { const double v = A[t][j]; if (j != t) off += v * v; else dia += v * v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dia += __shfl_xor(dia, o, 64); }
+    if (off <= 1e-30 * dia) break;                       // (uniform: the butterfly leaves the same sums in every lane)
     for (int round = 0; round < ne - 1; ++round) {
       __syncthreads();
       if (t < half) {                                    // pair t of this round: circle method with player ne - 1 fixed
