@@ -611,15 +611,19 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs g) {
   double* Cb = g.C + (g.tabC ? g.tabC[z] : (int64_t)z * g.bsC);
   // 8 elements per thread and pass, every load of a pass issued before the first use: the earlier one-element loop
   // waited out a full memory round trip per element (23 us per launch for a few MB of traffic)
+  // gridDim.y workgroups share a tile (a 64x64 tile is two passes of 8 elements per thread for one workgroup: four
+  // workgroups of half a pass each cut the launch from 9-15 us to the latency of one round of loads)
   constexpr int UNR = 8;
-  for (int e0 = threadIdx.x; e0 < BM * BN; e0 += 256 * UNR) {
+  const int per = (BM * BN + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int ebeg = (int)blockIdx.y * per, eend = (ebeg + per < BM * BN) ? ebeg + per : BM * BN;
+  for (int e0 = ebeg + threadIdx.x; e0 < eend; e0 += 256 * UNR) {
     double sacc[UNR], cv[UNR];
     double* pp[UNR];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
       const int e = e0 + 256 * q;
       const int m = e % BM, n = e / BM;
-      const bool ok = (e < BM * BN) && (m0 + m < g.M) && (n0 + n < g.N);
+      const bool ok = (e < eend) && (m0 + m < g.M) && (n0 + n < g.N);
       const int gn = n0 + n;
       pp[q] = !ok ? nullptr
                   : ((g.tabC2 != nullptr && gn >= g.splitN) ? g.C + g.tabC2[z] + (m0 + m) + (int64_t)(gn - g.splitN) * g.ldc
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs g) {
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
         const int e = e0 + 256 * q;
-        if (e < BM * BN) sacc[q] += g.sk_ws[(int64_t)(g.sk_split_major ? w - tz - 1 : w) * BM * BN + e];
+        if (e < eend) sacc[q] += g.sk_ws[(int64_t)(g.sk_split_major ? w - tz - 1 : w) * BM * BN + e];
       }
     }
 #pragma unroll
@@ -772,7 +776,7 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
         e = launch_one(gemm_sk_f64_kernel<BM, BN, TA, TB, ALIGNED>, a0, sgrid, smem, g, s, false, &r);
       }
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN>), dim3(tilesM * tilesN * g.batch), dim3(256), 0, s, g);
+      hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN>), dim3(tilesM * tilesN * g.batch, (BM * BN) / 1024), dim3(256), 0, s, g);
       // the event window covers the split GEMM AND its fixup launch: the flops credited are those of the whole stage
       if (prof) { (void)hipEventRecord(r.e1, s); prof_push(r); }
       return hipGetLastError();
