@@ -203,7 +203,7 @@ def dmrg_sweep(psi, H, envs, eigalg: Arnoldi, ws=None):
     visits = list(range(0, L - 1)) + list(range(L - 1, 0, -1))
     # galerkin norms stay on the device until the sweep is over (one read-back instead of two stream stalls per site)
     defer = hasattr(be, "nrm2_dev")
-    gslot = (ws if ws is not None else krylov.KrylovWorkspace(be)).get((len(visits), 1), 1)[0] if defer else None   # (2-D key: never the solver's 1-D slot)
+    gslot = (ws if ws is not None else krylov.KrylovWorkspace(be)).get((len(visits), 1), 1, tag="galerkin")[0] if defer else None   # (own tag: never a solver buffer)
     eps_s = [0.0] * L
     for iv, pos in enumerate(visits):
         h = envs.site_op(pos, psi) if hasattr(envs, "site_op") else ddAC(pos, psi, H, envs)

@@ -18,11 +18,14 @@ class KrylovWorkspace:
         self.be = be
         self.pool = {}
 
-    def get(self, shape, n):
-        key = tuple(shape)
-        lst = self.pool.setdefault(key, [])
+    def get(self, shape, n, tag=None):
+        """n device buffers of `shape`.  Buffers are pooled by (tag, shape): two users with different tags never share
+        a buffer even when their shapes coincide (the sweep's galerkin slot (2L-2, 1) and the fixed-budget solver's scalar
+        slot (m (2m+1) + 40, 1) have the same shape at L = 39 for m = 4, at L = 89 for m = 8)."""
+        shp = tuple(shape)
+        lst = self.pool.setdefault((tag, shp), [])
         while len(lst) < n:
-            lst.append(self.be.empty(*key))
+            lst.append(self.be.empty(*shp))
         return lst[:n]
 
 
@@ -57,10 +60,10 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
             # the whole solve as ONE library call (mpsk_hac_eigsolve_fixed): same kernels in the same order as below,
             # without the ~30 entry-point calls per site the host otherwise makes (they starve the stream at small D)
             out = be.empty(*shape)
-            scal = ws.get((m * stride + 40, 1), 1)[0]
+            scal = ws.get((m * stride + 40, 1), 1, tag="eigscal")[0]
             if matvec.eigsolve_fixed(start, m, V[:m + 1] + [ritz], scal, out, first_image) is not None:
                 return None, out, fixed_matvecs, None
-        slot = ws.get((m * stride,), 1)[0]
+        slot = ws.get((m * stride,), 1, tag="eigslot")[0]
         be.normalize_dev(start, out=V[0])              # no host round trip: the solve has ONE synchronisation, below
         for k in range(m):
             w = V[k + 1]
@@ -69,7 +72,7 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
                 be.axpby(1.0, w, 0.0, first_image)
             be.orth_step_dev(V[:k + 1], w, slot, k * stride)
         if not values and m <= 32 and hasattr(be, "ritz_dev"):
-            rb = ws.get((be.RITZ_BUF, 1), 1)[0]
+            rb = ws.get((be.RITZ_BUF, 1), 1, tag="ritz")[0]
             be.ritz_dev(m, stride, slot, rb)
             be.lincomb_dev(V[:m], rb, out=ritz)
             out = be.empty(*shape)

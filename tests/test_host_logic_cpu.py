@@ -467,3 +467,28 @@ def test_calc_galerkin_value_parity_host(cb):
     tests/test_gpu_traces.py::test_calc_galerkin_value_parity, same body)."""
     from test_gpu_traces import test_calc_galerkin_value_parity as body
     body(cb)
+
+
+@pytest.mark.parametrize("L,m", [(21, 4), (39, 4)])
+def test_sweep_galerkin_slot_does_not_alias_solver_buffers(cb, L, m):
+    """Regression: the sweep's galerkin slot (2L-2, 1) and the fixed-budget solver's scalar / Ritz buffers were
+    pooled by shape alone; at L = 21 (RITZ_BUF = 40) and L = 39 (m (2m+1) + 40 = 76 for m = 4) the shapes coincide and
+    the solver overwrote the stored galerkin values (max eps 2.0 on this very input before the fix).  Pools are tagged
+    now: eps_s of a fixed-budget sweep must equal the values of a sweep whose galerkin slot lives in a workspace of its own."""
+    Hg = mk.heisenberg_XXX(0.5, be=cb)
+    rng = np.random.default_rng(3)
+    dims = mo.FiniteMPS.random(L, 2, 4, np.random.default_rng(0)).bond_dims()
+    As = [rng.random((1 if i == 0 else dims[i - 1], 2, dims[i])) for i in range(L)]
+    eig = mk.Arnoldi(fixed_matvecs=m, krylovdim=m)
+    out = []
+    for shared in (True, False):
+        psi = mk.FiniteMPS(As, normalize=True, be=cb)
+        envs = mk.FinEnv(psi, Hg)
+        ws = krylov.KrylovWorkspace(cb)
+        if not shared:
+            orig = ws.get
+            side = krylov.KrylovWorkspace(cb)
+            ws.get = lambda shape, n, tag=None: (side.get(shape, n, tag) if tag == "galerkin" else orig(shape, n, tag))
+        out.append(np.array(alg.dmrg_sweep(psi, Hg, envs, eig, ws)))
+    assert np.all(np.isfinite(out[0])) and out[0].max() < 1.5
+    assert np.allclose(out[0], out[1], rtol=0, atol=1e-12)
