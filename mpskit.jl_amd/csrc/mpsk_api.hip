@@ -48,7 +48,7 @@ struct mpsk_mposlice {
   double O(int w, int t, int s, int v) const { return Ofull[w + (size_t)Wl * (t + d * (s + (size_t)d * v))]; }
 };
 
-struct PoolBuf { void* p; size_t bytes; bool used; };
+struct PoolBuf { void* p; size_t bytes; bool used; hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool ev_set = false; };
 
 struct mpsk_ctx {
   int device = 0;
@@ -138,6 +138,8 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
   HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+  gemm_retain_stream(c->stream);
+  gemm_retain_stream(c->stream2);
   *out = c;
   return MPSK_OK;
 }
@@ -145,12 +147,16 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
 int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (!c) return MPSK_OK;
   (void)hipSetDevice(c->device);
+  // a ctx destroyed inside a side-stream section or with a deferred factorization pending: route back to the main stream
+  // (otherwise the caller's stream would be destroyed below and the private one leaked) and complete the factorization
+  if (c->on_side) (void)mpsk_ctx_side_end(c);
+  if (c->pend.active) (void)mpsk_qr_commit(c, nullptr);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   gemm_release_stream(c->stream);     // split-K partial-tile workspaces attached to this ctx's streams
   gemm_release_stream(c->stream2);
   for (auto& kv : c->pair_plans) mix_plan_destroy(&kv.second);
-  for (auto& b : c->pool) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->pool) { if (b.p) (void)hipFree(b.p); if (b.ev) (void)hipEventDestroy(b.ev); }
   if (c->ws) (void)hipFree(c->ws);
   if (c->d_scal) (void)hipFree(c->d_scal);
   if (c->d_partial) (void)hipFree(c->d_partial);
@@ -171,10 +177,13 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
 
 int mpsk_ctx_set_stream(mpsk_ctx* c, void* s) {
   REQUIRE(c, "ctx is NULL");
+  REQUIRE(!c->on_side, "not inside a side-stream section (mpsk_ctx_side_end first)");
+  REQUIRE(!c->pend.active, "a deferred factorization is pending (mpsk_qr_commit first)");
   if (c->stream != (hipStream_t)s) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     gemm_release_stream(c->stream);
+    gemm_retain_stream((hipStream_t)s);
   }
   c->stream = (hipStream_t)s;
   return MPSK_OK;
@@ -206,6 +215,7 @@ int mpsk_ctx_synchronize(mpsk_ctx* c) {
 int mpsk_ctx_workspace_reserve(mpsk_ctx* c, size_t bytes) {
   REQUIRE(c, "ctx is NULL");
   if (bytes <= c->ws_bytes) return MPSK_OK;
+  REQUIRE(!c->on_side && !c->pend.active, "the workspace is in use (side-stream section / deferred factorization)");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->ws) HIPCHK(hipFree(c->ws));
@@ -675,6 +685,10 @@ static int pool_take(mpsk_ctx* c, size_t bytes, void** p, int* idx) {
     best = slot;
   }
   c->pool[best].used = true;
+  // the buffer's previous owner may have been applied on another stream (side-stream sections, rebound ctx): its last
+  // applications must have completed before the new owner overwrites GRc
+  if (c->pool[best].ev_set && c->pool[best].last != c->stream) (void)hipStreamWaitEvent(c->stream, c->pool[best].ev, 0);
+  c->pool[best].ev_set = false;
   *p = c->pool[best].p;
   *idx = best;
   return MPSK_OK;
@@ -753,7 +767,14 @@ int mpsk_hac_create(mpsk_ctx* c, const mpsk_mposlice* H, int Dlo, int Dl, int Dr
 
 int mpsk_hac_destroy(mpsk_hac* h) {
   if (!h) return MPSK_OK;
-  if (h->pool_idx >= 0 && h->pool_idx < (int)h->ctx->pool.size()) h->ctx->pool[h->pool_idx].used = false;
+  if (h->pool_idx >= 0 && h->pool_idx < (int)h->ctx->pool.size()) {
+    PoolBuf& b = h->ctx->pool[h->pool_idx];
+    b.used = false;
+    // stream ordering of the hand-back: everything enqueued so far on the ctx's current stream still reads the buffer
+    (void)hipSetDevice(h->ctx->device);
+    if (!b.ev) (void)hipEventCreateWithFlags(&b.ev, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (b.ev && hipEventRecord(b.ev, h->ctx->stream) == hipSuccess) { b.last = h->ctx->stream; b.ev_set = true; }
+  }
   if (h->ev_up) { (void)hipEventSynchronize(h->ev_up); (void)hipEventDestroy(h->ev_up); }   // zseg_host is still being read until then
   delete h;
   return MPSK_OK;
@@ -1252,6 +1273,8 @@ int mpsk_qrlq_pair(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1
   REQUIRE(c && A1 && Q1 && R1 && A2 && L2 && Q2, "NULL argument");
   REQUIRE(m >= n && n > 0, "needs m >= n > 0");
   REQUIRE(lda1 >= m && ldq1 >= m && ldr1 >= n && lda2 >= n && ldl2 >= n && ldq2 >= n, "leading dimension too small");
+  REQUIRE(!c->pend.active, "a deferred factorization is pending (mpsk_qr_commit first)");
+  c->defer_next = false;                       // deferral is defined for mpsk_qrpos2 / mpsk_lqpos only: this call completes at once
   HIPCHK(hipSetDevice(c->device));
   const size_t need = sizeof(double) * ((size_t)2 * m * n + (size_t)n * n + 8);
   if (c->ws3_bytes < need) {
@@ -1309,6 +1332,8 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
   const int kmax = m < n ? m : n;
   REQUIRE(ldt >= m && ldu >= m && ldv >= kmax, "leading dimension too small");
   REQUIRE(trunc_err >= 0.0, "trunc_err must be >= 0");
+  REQUIRE(!c->pend.active, "a deferred factorization is pending (mpsk_qr_commit first)");
+  c->defer_next = false;
   HIPCHK(hipSetDevice(c->device));
   std::string err;
   const int mm = m < n ? n : m, nn = m < n ? m : n, transposed = m < n ? 1 : 0;
@@ -1354,6 +1379,8 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   REQUIRE(nn > 64, "mpsk_tsplit needs min(m, n) > 64 (use mpsk_tsvd for small tensors)");
   REQUIRE(ldt >= m && ldal >= m && ldc >= 1 && ldar >= 1, "leading dimension too small");
   REQUIRE(trunc_err >= 0.0, "trunc_err must be >= 0");
+  REQUIRE(!c->pend.active, "a deferred factorization is pending (mpsk_qr_commit first)");
+  c->defer_next = false;                       // (the inner mpsk_qrpos / mpsk_lqpos calls complete at once)
   HIPCHK(hipSetDevice(c->device));
   const auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };
   const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);

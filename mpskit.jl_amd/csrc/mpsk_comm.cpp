@@ -51,7 +51,7 @@ int mpsk_comm_create(mpsk_ctx* ctx, int world, int rank, const void* id, mpsk_co
 int mpsk_comm_destroy(mpsk_comm* c) {
   if (!c) return MPSK_OK;
   (void)hipSetDevice(c->device);
-  (void)mpsk_ctx_synchronize(c->ctx);
+  (void)hipDeviceSynchronize();          // (not through c->ctx: the ctx may already have been destroyed by the caller)
   (void)ncclCommDestroy(c->nc);
   delete c;
   return MPSK_OK;

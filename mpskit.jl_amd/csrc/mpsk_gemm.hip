@@ -837,22 +837,28 @@ static bool g_splitk_enabled = (getenv("MPSK_SPLITK") == nullptr) || (getenv("MP
 static int g_splitk_force = getenv("MPSK_SPLITK_F") ? atoi(getenv("MPSK_SPLITK_F")) : 0;
 constexpr size_t SK_WS_DOUBLES = (size_t)1024 * 128 * 128 / 2;   // 512 slots of 128x128 == 2048 slots of 64x64
 // partial-tile workspace: one per (device, stream) so that concurrent streams never share slots (launches on ONE
-// stream are ordered, so ctxs that share a stream may share its slots); allocated on first use (64 MiB each), freed by
-// gemm_release_stream when the owning ctx is destroyed.  The table is mutex-protected: distinct ctxs launch from
+// stream are ordered, so ctxs that share a stream may share its slots); allocated on first use (64 MiB each), reference
+// counted by the ctxs bound to the stream (gemm_retain_stream / gemm_release_stream) and freed with the last of them.  The table is mutex-protected: distinct ctxs launch from
 // distinct host threads.
 static std::mutex g_skws_mu;
-static std::map<std::pair<int, hipStream_t>, double*> g_skws;
+struct SkWs { double* p = nullptr; int refs = 0; };     // refs: ctxs currently bound to the stream (gemm_retain_stream)
+static std::map<std::pair<int, hipStream_t>, SkWs> g_skws;
 static double* sk_workspace(hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lk(g_skws_mu);
-  auto key = std::make_pair(dev, s);
-  auto it = g_skws.find(key);
-  if (it != g_skws.end()) return it->second;
-  double* p = nullptr;
-  if (hipMalloc(&p, SK_WS_DOUBLES * sizeof(double)) != hipSuccess) return nullptr;
-  g_skws[key] = p;
-  return p;
+  SkWs& e = g_skws[std::make_pair(dev, s)];
+  if (e.p) return e.p;
+  if (hipMalloc(&e.p, SK_WS_DOUBLES * sizeof(double)) != hipSuccess) { e.p = nullptr; return nullptr; }
+  return e.p;
+}
+// Several ctxs may be bound to one stream (every Backend binds torch's current stream by default): the workspace of a
+// (device, stream) is freed when the LAST ctx bound to it lets go, never under a ctx that still launches on it.
+void gemm_retain_stream(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(g_skws_mu);
+  g_skws[std::make_pair(dev, s)].refs++;
 }
 void gemm_release_stream(hipStream_t s) {
   int dev = 0;
@@ -862,10 +868,11 @@ void gemm_release_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_skws_mu);
     auto it = g_skws.find(std::make_pair(dev, s));
     if (it == g_skws.end()) return;
-    p = it->second;
+    if (--it->second.refs > 0) return;
+    p = it->second.p;
     g_skws.erase(it);
   }
-  if (p) (void)hipFree(p);
+  if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); }
 }
 
 hipError_t gemm_f64(const GemmArgs& g_in, hipStream_t s) {

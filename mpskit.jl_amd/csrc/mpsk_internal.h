@@ -75,8 +75,9 @@ struct GemmArgs {
 
 hipError_t gemm_f64(const GemmArgs& g, hipStream_t s);
 void gemm_force_tile(int bm, int bn);
-// frees the split-K partial-tile workspace attached to (current device, stream); called when a ctx that owns or was
-// bound to the stream is destroyed (the stream must be idle)
+// reference count of the ctxs bound to (current device, stream); the split-K partial-tile workspace attached to the pair is
+// freed when the last of them releases it (ctx destroyed or bound to another stream)
+void gemm_retain_stream(hipStream_t s);
 void gemm_release_stream(hipStream_t s);
 void gemm_enable_streamk(bool on);
 void gemm_prof_enable(bool on);

@@ -599,6 +599,37 @@ def test_deferred_gauge_completion(be):
     assert relerr(be.download(L), La) < 1e-12 and relerr(be.download(Ql), Qla) < 1e-12
 
 
+def test_defer_is_not_inherited_by_composite_entry_points(be):
+    """mpsk_ctx_qr_defer arms the NEXT mpsk_qrpos2 / mpsk_lqpos; mpsk_qrlq_pair, mpsk_tsplit and mpsk_tsvd call
+    those internally and read the factors right away, so they clear the flag on entry (and refuse a pending deferral)."""
+    from mpskit_jl_amd._lib import MpskError
+    rng = np.random.default_rng(77)
+    m, n = 768, 384
+    A1, A2 = rng.random((m, n)), rng.standard_normal((n, m))
+    Qs, Rs = (be.download(t) for t in be.qrpos(be.upload(A1)))
+    Ls, Qls = (be.download(t) for t in be.lqpos(be.upload(A2)))
+    be.qr_defer()
+    Q1, R1, L2, Q2 = (be.download(t) for t in be.qrlq_pair(be.upload(A1), be.upload(A2)))
+    assert be.qr_commit() == 0                                    # nothing was left pending
+    assert relerr(Q1, Qs) < 1e-12 and relerr(R1, Rs) < 1e-12 and relerr(L2, Ls) < 1e-11 and relerr(Q2, Qls) < 1e-10
+    th = rng.standard_normal((512, 384))
+    be.qr_defer()
+    al, c, ar, k, _ = be.tsplit(be.upload(th), max_keep=100)
+    assert be.qr_commit() == 0
+    al, c, ar = be.download(al), be.download(c), be.download(ar)
+    U, S, Vh = np.linalg.svd(th, full_matrices=False)
+    assert relerr(al @ c @ ar, (U[:, :100] * S[:100]) @ Vh[:100]) < 1e-11
+    # a pending deferral is refused by the composite calls
+    be.qr_defer()
+    d1, d2 = be.upload(A1), be.upload(A1 + 1.0)
+    be.qrpos2(d1, d2)
+    with pytest.raises(MpskError):
+        be.qrlq_pair(be.upload(A1), be.upload(A2))
+    with pytest.raises(MpskError):
+        be.tsplit(be.upload(th), max_keep=100)
+    be.qr_commit()
+
+
 def test_cholqr_shift_retry(be):
     """The first CholeskyQR3 attempt uses a shift at the rounding level of the Gram matrix; on a matrix whose Gram matrix is
     numerically indefinite (cond 1e12) the device flags the breakdown and the factorization is repeated with the shift of
