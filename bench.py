@@ -10,9 +10,12 @@ site, on a seeded synthetic uniform[0,1) random MPS that 
 left-canonical and resident in HBM when the timed region starts.  N > 1: the bond index is
 block-sharded over the ranks -- storage-sharded environments, one in-place RCCL all-gather per
 matvec, one all-reduce per left-environment update (strong scaling: the same chain on N GPUs).
-After the timed steps ONE extra sweep runs in converged-tolerance mode (`to_tolerance`), and at
-N = 1 the oracle's CPU restatement is timed on the host cores (`cpu_baseline`).  Rank 0 prints
-ONE JSON line.
+After the timed steps two more legs run on FRESH copies of the initial state psi0 (so that they
+do not depend on --steps): `early_sweeps` = sweeps 1-2 from psi0 with the same fixed budget (the
+gauge steps of unconverged tensors are worse conditioned: CholeskyQR retries are counted), and
+`to_tolerance` = sweeps 1..T from psi0 with the reference's default eigensolver
+Arnoldi(tol=1e-12, krylovdim=30, maxiter=100) (defaults.jl:33).  At N = 1 the oracle's CPU
+restatement is timed on the host cores (`cpu_baseline`).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -142,7 +145,9 @@ def main():
     ap.add_argument("--D", type=int, default=1024)
     ap.add_argument("--matvecs", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tolerance-sweep", action="store_true", help="skip the extra converged-tolerance sweep")
+    ap.add_argument("--no-tolerance-sweep", action="store_true", help="skip the converged-tolerance leg")
+    ap.add_argument("--tol-sweeps", type=int, default=2, help="sweeps of the converged-tolerance leg (from psi0)")
+    ap.add_argument("--early-sweeps", type=int, default=2, help="fixed-budget sweeps from psi0 reported as `early_sweeps`")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded sweep (blocked vectors, storage-sharded environments, RCCL collectives) even with "
                          "one rank: exercises the N > 1 code path on a 1-GPU box")
@@ -188,11 +193,15 @@ def main():
     W = H[0].Wl
     rng = np.random.default_rng(20240213)          # same seed on every rank -> identical replicas
     psi = mk.FiniteMPS.random(L, d, D, rng, normalize=True, be=be)
+    psi0 = psi.copy()                              # (stored tensors are never modified in place: a shallow copy IS psi0)
     sharded = world > 1 or args.force_shard
     comm = Comm(world, rank, force_collective=args.force_shard) if sharded else None
     # N > 1: bond-sharded sweep -- storage-sharded environments (1/N per GPU), blocked Krylov vectors, one in-place
     # all-gather per matvec, one all-reduce per left-environment update, one gather per right-environment use
-    envs = ShardedFinEnv(psi, H, comm, force=args.force_shard) if sharded else mk.FinEnv(psi, H)
+    def make_envs(p):
+        return ShardedFinEnv(p, H, comm, force=args.force_shard) if sharded else mk.FinEnv(p, H)
+
+    envs = make_envs(psi)
     eig = mk.Arnoldi(fixed_matvecs=args.matvecs, krylovdim=max(args.matvecs, 2))
     ws = krylov.KrylovWorkspace(be)
 
@@ -270,10 +279,43 @@ def main():
     if world > 1:
         dist.barrier()
 
-    # converged-tolerance mode (SURVEY 8d / BASELINE.md section 3): ONE more sweep with the reference's default
-    # eigensolver, Arnoldi(tol = 1e-12, krylovdim = 30, eager) (defaults.jl:33) instead of the fixed budget
+    def qr_snapshot():
+        q = dict(be.qr_stats())
+        q["shift_retries"] = be.qr_retries()
+        return q
+
+    def energy(p, e):
+        try:
+            return float(np.sum(alg.expectation_value(p, H, e)))
+        except Exception:                           # (not every environment flavour serves expectation_value)
+            return None
+
+    # early sweeps: the SAME fixed-budget sweep, but on sweeps 1..k from psi0 (the timed steps above run on the state
+    # W + K sweeps have already converged; unconverged tensors make the gauge steps' Gram matrices worse conditioned)
+    early = None
+    if args.early_sweeps > 0:
+        p1 = psi0.copy()
+        e1 = make_envs(p1)
+        rows = []
+        for i in range(args.early_sweeps):
+            q0 = qr_snapshot()
+            barrier()
+            t0 = time.perf_counter()
+            eps_e = alg.dmrg_sweep(p1, H, e1, eig, ws)
+            barrier()
+            dt_e = time.perf_counter() - t0
+            q1 = qr_snapshot()
+            rows.append({"sweep": i + 1, "sweeps_per_s": round(1.0 / dt_e, 4), "ms": round(dt_e * 1e3, 1),
+                         "energy": energy(p1, e1), "max_galerkin": float(max(eps_e)),
+                         "qr_calls": {k: q1[k] - q0[k] for k in q1}})
+        early = {"from": "psi0 (fresh copy)", "fixed_matvecs": args.matvecs, "sweeps": rows}
+        del p1, e1
+
+    # converged-tolerance mode (SURVEY 8d / BASELINE.md section 3): sweeps 1..T from a fresh copy of psi0 with the
+    # reference's default eigensolver Arnoldi(tol = 1e-12, krylovdim = 30, maxiter = 100, eager) (defaults.jl:33,
+    # dmrg.jl:17) instead of the fixed budget -- independent of --steps
     to_tol = None
-    if not args.no_tolerance_sweep:
+    if not args.no_tolerance_sweep and args.tol_sweeps > 0:
         nmv = {"n": 0}
         orig_eig = krylov.eigsolve_sr
 
@@ -283,18 +325,31 @@ def main():
             return r
 
         krylov.eigsolve_sr = counting
+        p2 = psi0.copy()
+        e2 = make_envs(p2)
+        rows = []
         try:
-            barrier()
-            t0 = time.perf_counter()
-            eps_t = alg.dmrg_sweep(psi, H, envs, mk.Arnoldi(tol=1e-12, krylovdim=30, maxiter=1), ws)
-            barrier()
-            dt_t = time.perf_counter() - t0
+            for i in range(args.tol_sweeps):
+                n0, q0 = nmv["n"], qr_snapshot()
+                barrier()
+                t0 = time.perf_counter()
+                eps_t = alg.dmrg_sweep(p2, H, e2, mk.Arnoldi(tol=1e-12, krylovdim=30, maxiter=100), ws)
+                barrier()
+                dt_t = time.perf_counter() - t0
+                q1 = qr_snapshot()
+                rows.append({"sweep": i + 1, "sweeps_per_s": round(1.0 / dt_t, 4), "ms": round(dt_t * 1e3, 1),
+                             "energy": energy(p2, e2), "matvecs": nmv["n"] - n0,
+                             "matvecs_per_site_mean": round((nmv["n"] - n0) / (2 * L - 2), 2),
+                             "max_galerkin": float(max(eps_t)), "qr_calls": {k: q1[k] - q0[k] for k in q1}})
         finally:
             krylov.eigsolve_sr = orig_eig
-        to_tol = {"sweeps_per_s": round(1.0 / dt_t, 4), "ms_per_sweep": round(dt_t * 1e3, 1),
-                  "eigensolver": "Arnoldi(tol=1e-12, krylovdim=30, eager), one Krylov cycle per site",
-                  "matvecs_per_site_mean": round(nmv["n"] / (2 * L - 2), 2),
-                  "max_galerkin": float(max(eps_t))}
+        tot_ms = sum(r["ms"] for r in rows)
+        to_tol = {"from": "psi0 (fresh copy)", "eigensolver": "Arnoldi(tol=1e-12, krylovdim=30, maxiter=100, eager)",
+                  "sweeps_per_s": round(len(rows) / (tot_ms * 1e-3), 4),
+                  "matvecs_total": sum(r["matvecs"] for r in rows),
+                  "matvecs_per_site_mean": round(sum(r["matvecs"] for r in rows) / (len(rows) * (2 * L - 2)), 2),
+                  "sweeps": rows}
+        del p2, e2
 
     if rank == 0:
         out = {
@@ -310,6 +365,7 @@ def main():
             "dAC_tflops": None if dac_tflops is None else round(dac_tflops, 3),
             "dAC_frac_of_fp64_mfma_peak": None if dac_tflops is None else round(dac_tflops / FP64_MFMA_PEAK_TFLOPS, 4),
             "operator_applications_per_site": args.matvecs,       # the galerkin image reuses the eigensolver's first matvec
+            "early_sweeps": early,
             "to_tolerance": to_tol,
             "max_galerkin_last_sweep": None if eps is None else float(max(eps)),
             "qr_calls_timed": qr_timed,

@@ -22,7 +22,9 @@ def _traces():
 
 def test_fixture_files_cover_the_baseline_configs():
     tr = _traces()
-    assert set(tr) == set(gen.SWEEP_CASES)
+    assert set(tr) == set(gen.SWEEP_CASES) | set(gen.VUMPS_CASES)
+    ts = np.load(os.path.join(GOLD, "tsplit_4096.npz"))
+    assert ts["S"].shape == (gen.TSPLIT_N,) and int(ts["keep"]) == gen.TSPLIT_KEEP
     fx = np.load(os.path.join(GOLD, "projected_D1024.npz"))
     for case, c in gen.PROJ_CASES.items():
         for op in c["ops"]:
@@ -82,3 +84,36 @@ def test_projected_fixture_oracle_regression():
     assert abs(nrm - float(fx[f"{case}.dAC.norm"])) <= 1e-13 * nrm
     assert np.abs(proj - fx[f"{case}.dAC.proj"]).max() <= 1e-12 * nrm
     assert np.abs(samp - fx[f"{case}.dAC.samp"]).max() <= 1e-12 * nrm / np.sqrt(y.size) * 10
+
+
+def test_round3_fixtures_are_pinned_by_independent_answers():
+    """The fixtures added in round 3 against answers that do not come from the oracle's own drivers:
+    * Hubbard L = 8 two-site DMRG at the exact bond dimension (4^4 = 256) == sparse ED of the same MPO (1e-12);
+    * VUMPS iTFI g = 0.5 at D = 64 == the energy density the reference's docs record (3.ising-dqpt/index.md:118);
+    * the 4096 LAPACK singular values of the seeded theta == the designed spectrum to LAPACK's absolute accuracy, and the
+      stored discarded weight is the tail sum at k = 1024."""
+    tr = _traces()
+    hb = tr["c4_hubbard_L8_D256_exact"]
+    assert abs(hb["trace"][-1][1] - hb["ed_ground_energy"]) <= 1e-12 * abs(hb["ed_ground_energy"])
+    assert max(hb["schmidt"]) < 1.0 and len(hb["schmidt"]) == 256
+    # the sparse ED builder itself against the oracle's dense Hamiltonian (L = 4: 256 x 256) and dense ED
+    H = mo.hubbard_mpo(1.0, 4.0)
+    e4 = np.linalg.eigvalsh(mo.dense_hamiltonian(H, 4))[0]
+    assert abs(gen.ed_ground_energy(mo, H, 4) - e4) <= 1e-11 * abs(e4)
+    v = tr["c3_itfi_D64"]
+    assert abs(v["trace"][-1][1] - (-1.063544409973)) < 2e-12
+    assert v["trace"][-1][2] < 1e-11
+    ts = np.load(os.path.join(GOLD, "tsplit_4096.npz"))
+    design = np.sort(gen.tsplit_spectrum())[::-1]
+    assert np.abs(ts["S"] - design).max() <= 1e-14 * design[0]
+    assert abs(float(ts["disc"]) - np.sqrt(np.sum(design[gen.TSPLIT_KEEP:] ** 2))) <= 1e-9 * float(ts["disc"])
+    assert design[1022] == design[1025] and design[1021] > design[1022] > design[1026]      # the quadruplet across the cut
+
+
+def test_vumps_fixture_oracle_regression():
+    """The oracle still reproduces the committed config-3 trace at D = 64 iteration by iteration (about 3 s)."""
+    fx = _traces()["c3_itfi_D64"]
+    out = gen.run_vumps_case(mo, "c3_itfi_D64")
+    assert len(out["trace"]) == len(fx["trace"])
+    for (i, E, e), (io, Eo, eo) in zip(out["trace"], fx["trace"]):
+        assert i == io and abs(E - Eo) <= 1e-12 * abs(Eo)

@@ -124,3 +124,35 @@ def test_full_size_two_site_split_properties(be):
     assert float((alT @ cT @ arT - proj).abs().max()) < 1e-11 * float(A.abs().max())
     sv = torch.linalg.svdvals(cT).cpu().numpy()
     assert np.abs(sv - S).max() < 1e-12 * S[0]
+
+
+def test_tsplit_4096_singular_values_pinned_by_lapack(be):
+    """tsvd!(theta; trunc = truncdim(1024)) at the config-4 split size against LAPACK (dmrg.jl:96-104: the truncation acts
+    on exactly these values).  tests/golden/tsplit_4096.npz holds numpy.linalg.svd's 4096 singular values and the discarded
+    weight of a seeded graded theta with exact multiplets (one across the cut); theta is regenerated from the seed here.
+    Absolute accuracy 1e-12 S[0] on every value, 1e-8 relative on the kept ones (LAPACK's own values are only good to
+    ~1e-16 S[0] absolute, i.e. 1e-10 relative at S[1023] = 1.2e-6), discarded weight to 1e-9 relative, isometries."""
+    import sys, os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, gold)
+    import make_sweep_traces as gen
+    fx = np.load(os.path.join(gold, "tsplit_4096.npz"))
+    Sref, k = fx["S"], int(fx["keep"])
+    th = gen.tsplit_theta()
+    assert np.abs(th.ravel()[:: 1048583][:16] - fx["theta_samples"]).max() < 1e-12        # same theta as the fixture's
+    n = th.shape[0]
+    d_th = be.upload(th)
+    al, c, ar, S, disc = be.tsplit(d_th, max_keep=k)
+    assert len(S) == k
+    assert np.abs(S - Sref[:k]).max() <= 1e-12 * Sref[0]
+    assert np.abs(S / Sref[:k] - 1.0).max() <= 1e-8
+    assert abs(disc - float(fx["disc"])) <= 1e-9 * float(fx["disc"])
+    A, Cm, B = be.download(al), be.download(c), be.download(ar)
+    assert np.abs(A.T @ A - np.eye(k)).max() < 1e-12 and np.abs(B @ B.T - np.eye(k)).max() < 1e-12
+    # al c ar == the rank-k truncation of theta up to the freedom inside the multiplet that straddles the cut:
+    # |theta - al c ar|_F = discarded weight (optimal rank-k error) to 1e-9 relative
+    assert abs(np.linalg.norm(th - A @ Cm @ B) - float(fx["disc"])) <= 1e-9 * float(fx["disc"]) + 1e-13 * float(fx["theta_fro"])
+    # the full decomposition (mpsk_tsvd, rotations accumulated): every one of the 4096 values
+    U, Sd, Vh, kept, _ = be.tsvd(d_th)
+    Sf = be.download(Sd).ravel()
+    assert kept == n and np.abs(Sf - Sref).max() <= 1e-12 * Sref[0]
