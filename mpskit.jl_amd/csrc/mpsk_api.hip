@@ -72,6 +72,7 @@ struct mpsk_ctx {
   double qr_shift_fast = getenv("MPSK_CQ_SHIFT_SCALE") ? atof(getenv("MPSK_CQ_SHIFT_SCALE")) : 1.0e-8;
   // second stream + workspace for two concurrent factorizations (mpsk_qrpos2)
   hipStream_t stream2 = nullptr;
+  hipStream_t xstreams[3] = {nullptr, nullptr, nullptr};   // {stream2, two more}: chains of the block-Jacobi schedule (mpsk_svd.hip)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* ws2 = nullptr;
   size_t ws2_bytes = 0;
@@ -136,10 +137,15 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
   HIPCHK(hipMalloc(&c->d_flag, 64));
   HIPCHK(hipHostMalloc(&c->h_flags, 64, hipHostMallocDefault));
   HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  c->xstreams[0] = c->stream2;
+  HIPCHK(hipStreamCreateWithFlags(&c->xstreams[1], hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->xstreams[2], hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
   gemm_retain_stream(c->stream);
   gemm_retain_stream(c->stream2);
+  gemm_retain_stream(c->xstreams[1]);
+  gemm_retain_stream(c->xstreams[2]);
   *out = c;
   return MPSK_OK;
 }
@@ -168,6 +174,8 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->ws2) (void)hipFree(c->ws2);
   if (c->ws3) (void)hipFree(c->ws3);
+  for (int i = 1; i < 3; ++i)
+    if (c->xstreams[i]) { (void)hipStreamSynchronize(c->xstreams[i]); gemm_release_stream(c->xstreams[i]); (void)hipStreamDestroy(c->xstreams[i]); }
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1355,13 +1363,13 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
     }
     if (int rc = qrpos_dispatch(c, mm, nn, Ap, lda, Qb, mm, Rb, nn, rest)) return rc;
     hipError_t e = tsvd(nn, nn, Rb, nn, (double*)U, ldu, (double*)S, (double*)Vh, ldv, max_keep, trunc_err, kept,
-                        disc_norm, rest, c->stream, &err, &c->last_svd_sweeps, Qb, mm, mm, transposed, c->stream2);
+                        disc_norm, rest, c->stream, &err, &c->last_svd_sweeps, Qb, mm, mm, transposed, c->xstreams, 3);
     if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
     return MPSK_OK;
   }
   if (int rc = ensure_ws(c, tsvd_workspace_bytes(m, n))) return rc;
   hipError_t e = tsvd(m, n, (const double*)theta, ldt, (double*)U, ldu, (double*)S, (double*)Vh, ldv, max_keep,
-                      trunc_err, kept, disc_norm, c->ws, c->stream, &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->stream2);
+                      trunc_err, kept, disc_norm, c->ws, c->stream, &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->xstreams, 3);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsvd: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
   return MPSK_OK;
 }
@@ -1420,7 +1428,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   }
   std::string err;
   hipError_t e = tsvd(nn, nn, Rb, nn, Y, nn, (double*)S, nullptr, 1, max_keep, trunc_err, kept, disc_norm, c->ws, c->stream,
-                      &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->stream2, /*vfree=*/1);
+                      &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->xstreams, 3, /*vfree=*/1);
   if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
   const int k = *kept;
   REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");

@@ -151,6 +151,6 @@ size_t tsvd_workspace_bytes(int m, int n);
 hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
                 int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,
                 std::string* err, int* sweeps_out, const double* Qpre = nullptr, int ldq = 0, int q_rows = 0,
-                int outer_transposed = 0, hipStream_t s2 = nullptr, int vfree = 0);
+                int outer_transposed = 0, const hipStream_t* xs = nullptr, int nxs = 0, int vfree = 0);
 
 }  // namespace mpsk

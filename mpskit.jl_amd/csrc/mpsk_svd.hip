@@ -365,6 +365,93 @@ struct SvdPlan {
   size_t bytes;
 };
 
+// ---- chained tournament ---------------------------------------------------------------------------------------------
+// The rotation kernel is latency-bound (one workgroup per pair, ~100 us) and leaves most of the chip idle, while the Gram
+// and update GEMMs of a round are bandwidth-bound full-chip launches.  A plain round-robin round is three DEPENDENT
+// launches, so the two kinds of work never overlap.  The sweep is therefore re-ordered into NC independent CHAINS
+// (sub-tournaments over disjoint block sets, each on its own stream, no events inside a stage):
+//   the 2P column blocks form 2 NC groups of pc = P / NC blocks;
+//   stage A : chain c runs a full round-robin on the union of two groups                   (2 pc - 1 rounds, pc pairs each)
+//   stage B : the remaining group pairs follow a 1-factorisation of K_{2NC} (circle method) whose first matching is the
+//             set of unions of stage A; per matching every chain runs the bipartite tournament of one group pair
+//                                                                                         (2 NC - 2 matchings x pc rounds)
+// = 2P - 1 rounds and every pair of blocks exactly once per sweep, as in the plain order.  The rotations of one chain run
+// under the GEMMs of the others.  The block -> slot permutation between rounds is only a table of C offsets of the update
+// GEMM (one table per round); the LAST round of a stage writes blocks into other chains' slot ranges and is bracketed by
+// two all-stream barriers (2 (2 NC - 1) per sweep).  NC = 2 is the "phased" schedule of round 2.
+struct ChainSched {
+  int NC = 1, pc = 0, rounds = 0;
+  std::vector<int> blk;           // [rounds][P][2]: logical block in (pair slot p, half h); block ids = round-0 slots
+  std::vector<char> stage_first, stage_last;
+};
+
+static bool build_chain_schedule(int P, int NC, ChainSched* sc) {
+  if (NC < 2 || P % NC != 0 || P / NC < 2) return false;
+  const int pc = P / NC, NG = 2 * NC, M = NG - 1, T = NG - 1;
+  sc->NC = NC; sc->pc = pc; sc->rounds = 2 * P - 1;
+  sc->blk.assign((size_t)sc->rounds * P * 2, -1);
+  sc->stage_first.assign(sc->rounds, 0);
+  sc->stage_last.assign(sc->rounds, 0);
+  auto matching = [&](int r, std::vector<std::pair<int, int>>* out) {
+    out->clear();
+    out->push_back({T, r % M});
+    for (int k = 1; k < NC; ++k) out->push_back({(r + k) % M, ((r - k) % M + M) % M});
+  };
+  std::vector<std::pair<int, int>> mt;
+  int r = 0;
+  // stage A
+  matching(0, &mt);
+  sc->stage_first[0] = 1;
+  const int n2 = 2 * pc;
+  for (int t = 0; t < n2 - 1; ++t, ++r) {
+    for (int c = 0; c < NC; ++c) {
+      std::vector<int> B(n2), arr(n2);
+      for (int i = 0; i < pc; ++i) { B[i] = mt[c].first * pc + i; B[pc + i] = mt[c].second * pc + i; }
+      for (int i = 0; i < n2 - 1; ++i) arr[i] = B[(i + t) % (n2 - 1)];
+      arr[n2 - 1] = B[n2 - 1];
+      for (int i = 0; i < pc; ++i) {
+        int* e = &sc->blk[((size_t)r * P + c * pc + i) * 2];
+        e[0] = arr[i]; e[1] = arr[n2 - 1 - i];
+      }
+    }
+  }
+  sc->stage_last[r - 1] = 1;
+  // stage B
+  for (int sm = 1; sm <= NG - 2; ++sm) {
+    matching(sm, &mt);
+    sc->stage_first[r] = 1;
+    for (int t = 0; t < pc; ++t, ++r)
+      for (int c = 0; c < NC; ++c)
+        for (int i = 0; i < pc; ++i) {
+          int* e = &sc->blk[((size_t)r * P + c * pc + i) * 2];
+          e[0] = mt[c].first * pc + i; e[1] = mt[c].second * pc + (i + t) % pc;
+        }
+    sc->stage_last[r - 1] = 1;
+  }
+  if (r != sc->rounds) return false;
+  // relabel: block id = its slot in round 0 (the initial column order of G)
+  std::vector<int> slot0(2 * P, -1);
+  for (int p = 0; p < P; ++p) for (int h = 0; h < 2; ++h) slot0[sc->blk[((size_t)p) * 2 + h]] = 2 * p + h;
+  for (int b = 0; b < 2 * P; ++b) if (slot0[b] < 0) return false;
+  for (auto& v : sc->blk) v = slot0[v];
+  // every unordered pair of blocks exactly once
+  std::vector<char> seen((size_t)4 * P * P, 0);
+  for (int rr = 0; rr < sc->rounds; ++rr)
+    for (int p = 0; p < P; ++p) {
+      const int a = sc->blk[((size_t)rr * P + p) * 2], b = sc->blk[((size_t)rr * P + p) * 2 + 1];
+      if (a == b || seen[(size_t)a * 2 * P + b]) return false;
+      seen[(size_t)a * 2 * P + b] = seen[(size_t)b * 2 * P + a] = 1;
+    }
+  return true;
+}
+
+static int svd_default_chains(int P) {
+  int nc = (P >= 32 && P % 4 == 0) ? 4 : ((P >= 16 && P % 2 == 0) ? 2 : 1);
+  if (const char* ev = getenv("MPSK_SVD_CHAINS")) { const int v = atoi(ev); if (v >= 1 && v <= 8) nc = v; }
+  if (nc > 1 && (P % nc != 0 || P / nc < 2)) nc = 1;
+  return nc;
+}
+
 static SvdPlan svd_plan(int m, int n) {
   SvdPlan p;
   p.transposed = (m < n);
@@ -382,7 +469,9 @@ static SvdPlan svd_plan(int m, int n) {
   p.Q = q;
   size_t d = (size_t)2 * p.mm * p.npad + (size_t)2 * p.nn * p.npad + (size_t)p.P * p.Q * J2 * J2 +
              (size_t)2 * p.P * J2 * J2 + (size_t)p.npad * 2 + 64;
-  size_t tabs = (size_t)16 * (2 * p.P) * sizeof(int64_t) + (size_t)p.P * p.Q * 2 * sizeof(int64_t) + 256;
+  // tables: five fixed 2P-entry tables, the Gram tables, and (chained schedule) two destination tables per round
+  size_t tabs = (size_t)8 * (2 * p.P) * sizeof(int64_t) + (size_t)p.P * p.Q * 2 * sizeof(int64_t) +
+                (size_t)2 * (2 * p.P) * (2 * p.P) * sizeof(int64_t) + 256;
   p.bytes = d * sizeof(double) + tabs + (size_t)p.npad * sizeof(int);
   return p;
 }
@@ -396,20 +485,21 @@ size_t tsvd_workspace_bytes(int m, int n) { return svd_plan(m, n).bytes; }
 // on the columns of R^T, which are far closer to orthogonal than those of A' (graded spectra -- the DMRG
 // case -- stagnate for tens of sweeps without it):  R^T = G W^T  =>  A' = (Qpre W) Sigma (G Sigma^-1)^T.
 // outer_transposed says whether A' was theta^T, i.e. which factor is U and which is Vh.
+// xs[0 .. nxs): extra streams of the calling ctx for the chained schedule (xs[0] also serves the V accumulation of the
+// unchained order); the main stream s is chain 0.
 hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, double* S, double* Vh, int ldv,
                 int max_keep, double trunc_err, int* kept, double* disc_norm, void* ws, hipStream_t s,
                 std::string* err, int* sweeps_out, const double* Qpre, int ldq, int q_rows, int outer_transposed,
-                hipStream_t s2, int vfree) {
+                const hipStream_t* xs, int nxs, int vfree) {
   // vfree: theta := R (n x n) of a QR-preconditioned problem, Jacobi on R^T WITHOUT accumulating the rotations
   // (a third of the per-round traffic): returns S and, in U (n x kmax, ldu), the normalised sorted columns of the
   // converged G = R^T W, i.e. the RIGHT singular vectors of R (and of the matrix R came from).  The caller rebuilds the
   // other factor from the original matrix (mpsk_tsplit).
   SvdPlan pl = svd_plan(m, n);
-  hipStream_t s_phase = s2;                // second stream of the phased V-free schedule (below)
+  hipStream_t s2 = (nxs > 0 && xs) ? xs[0] : nullptr;
   if (vfree) {
     if (m != n) return hipErrorInvalidValue;
     pl.transposed = 1;
-    s2 = nullptr;
   }
   if (Qpre) {
     if (m != n) return hipErrorInvalidValue;
@@ -435,8 +525,9 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   int64_t* t_updB = t_updA_V + 2 * P;
   int64_t* t_updC_G = t_updB + 2 * P;
   int64_t* t_updC_V = t_updC_G + 2 * P;
-  int64_t* t_phase = t_updC_V + 2 * P;     // 5 destination tables x 2P entries (phased schedule)
-  int* d_perm = (int*)(t_phase + 10 * P);
+  int64_t* t_destG = t_updC_V + 2 * P;                 // chained schedule: [rounds][2][P] destination offsets (G)
+  int64_t* t_destV = t_destG + (size_t)(2 * P) * (2 * P);   //                                                     (V)
+  int* d_perm = (int*)(t_destV + (size_t)(2 * P) * (2 * P));
 
   // round-robin tournament on 2P blocks: slot 2p = top[p], 2p+1 = bottom[p]
   auto dest_slot = [&](int p, int half) -> int {
@@ -450,10 +541,17 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     return 2 * (p - 1) + 1;                // bottom[p] -> bottom[p-1]
   };
   const int kq = mm / Q;                   // rows per K-split (Q divides mm by construction)
-  std::vector<int64_t> h((size_t)2 * P * Q + 20 * P);
+  ChainSched csch;
+  int NC = svd_default_chains(P);
+  if (NC > 1 + nxs) NC = (1 + nxs >= 4) ? 4 : ((1 + nxs >= 2) ? 2 : 1);
+  if (NC > 1 && (P % NC != 0 || P / NC < 2 || !build_chain_schedule(P, NC, &csch))) NC = 1;
+  // host mirror of the device tables (one upload): Gram tables, five 2P-entry update tables, then -- chained schedule --
+  // the per-round destination tables of G and V at a fixed distance of (2P)^2 entries (rounds = 2P - 1 < 2P)
+  std::vector<int64_t> h((size_t)2 * P * Q + 10 * P + (NC > 1 ? 2 * (size_t)(2 * P) * (2 * P) : 0), 0);
   int64_t* hgA = h.data(); int64_t* hgC = hgA + (size_t)P * Q;
   int64_t* huAG = hgC + (size_t)P * Q; int64_t* huAV = huAG + 2 * P; int64_t* huB = huAV + 2 * P;
   int64_t* huCG = huB + 2 * P; int64_t* huCV = huCG + 2 * P;
+  int64_t* hdG = huCV + 2 * P; int64_t* hdV = hdG + (size_t)(2 * P) * (2 * P);
   for (int p = 0; p < P; ++p) {
     for (int q = 0; q < Q; ++q) {
       hgA[p * Q + q] = (int64_t)p * J2 * mm + (int64_t)q * kq;
@@ -468,53 +566,19 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     huCV[p] = (int64_t)dest_slot(p, 0) * JB * nn;
     huCV[P + p] = (int64_t)dest_slot(p, 1) * JB * nn;
   }
-  // ---- phased schedule (V-free mode, mpsk_tsplit) --------------------------------------------------------------------
-  // The rotation kernel is latency-bound (one workgroup per pair, ~100 us) and leaves most of the chip idle; cutting the
-  // plain round-robin into stream groups needs two cross-queue events per group and round, which cost more than the overlap
-  // returns (measured, see below).  Here the sweep is re-ordered into phases whose two halves are INDEPENDENT tournaments:
-  //   phase 1: round-robin inside the slot halves H1 = [0, P) and H2 = [P, 2P)               (P - 1 rounds, P/2 pairs each)
-  //   phase 2a: bipartite H1a x H2a and H1b x H2b (top stays, bottom shifts to the previous pair)   (P/2 rounds)
-  //   phase 2b: bipartite H1a x H2b and H1b x H2a                                                (P/2 rounds)
-  // = 2P - 1 rounds and every pair of blocks once, as before.  Each half runs on its own stream with no events inside a
-  // phase (the rotations of one half run under the GEMMs of the other); the LAST round of a phase writes the blocks where
-  // the next phase wants them (the permutation is only a table of C offsets of the update GEMM) and is bracketed by two
-  // stream barriers -- six per sweep.
-  const int H = P / 2;
-  bool phased = vfree && P >= 16 && (P % 4 == 0) && s_phase != nullptr && s_phase != s;
-  if (const char* ev = getenv("MPSK_SVD_PHASES")) { if (atoi(ev) == 0) phased = false; }
-  if (phased) {
-    int64_t* hph = huCV + 2 * P;           // follows the five 2P-entry arrays above
-    auto rr_local = [&](int pl_, int half, int Pi) -> int {       // dest_slot of the round-robin on Pi pairs
-      if (Pi == 1) return half;
-      if (half == 0) {
-        if (pl_ == 0) return 0;
-        if (pl_ + 1 <= Pi - 1) return 2 * (pl_ + 1);
-        return 2 * (Pi - 1) + 1;
-      }
-      if (pl_ == 0) return 2;
-      return 2 * (pl_ - 1) + 1;
-    };
-    auto t0 = [&](int pp, int half) -> int { const int inst = pp / H, pl_ = pp % H; return 2 * H * inst + rr_local(pl_, half, H); };
-    auto t2 = [&](int pp, int half) -> int {
-      if (half == 0) return 2 * pp;
-      const int inst = pp / H, pl_ = pp % H;
-      return 2 * (inst * H + (pl_ - 1 + H) % H) + 1;
-    };
-    for (int pp = 0; pp < P; ++pp)
-      for (int half = 0; half < 2; ++half) {
-        const int a = t0(pp, half);
-        int a_last;                          // phase 1 -> 2a: H1a -> tops of instance A, H1b -> tops of B, H2a / H2b -> bottoms
-        if (a < H) a_last = 2 * a;
-        else if (a < 2 * H) a_last = P + 2 * (a - H);
-        else if (a < 3 * H) a_last = 2 * (a - 2 * H) + 1;
-        else a_last = P + 2 * (a - 3 * H) + 1;
-        const int b = t2(pp, half);
-        const int q = b / 2;
-        const int b_lastA = (b & 1) ? 2 * ((q + H) % P) + 1 : b;          // 2a -> 2b: the bottoms change instance
-        const int b_lastB = (b & 1) ? P + q : q;                           // 2b -> phase 1: tops -> [0, P), bottoms -> [P, 2P)
-        const int dst[5] = {a, a_last, b, b_lastA, b_lastB};
-        for (int t = 0; t < 5; ++t) hph[(size_t)t * 2 * P + (size_t)half * P + pp] = (int64_t)dst[t] * JB * mm;
-      }
+  if (NC > 1) {
+    std::vector<int> slot_next(2 * P);
+    for (int r = 0; r < csch.rounds; ++r) {
+      const int rn = (r + 1) % csch.rounds;
+      for (int p = 0; p < P; ++p)
+        for (int hh = 0; hh < 2; ++hh) slot_next[csch.blk[((size_t)rn * P + p) * 2 + hh]] = 2 * p + hh;
+      for (int p = 0; p < P; ++p)
+        for (int hh = 0; hh < 2; ++hh) {
+          const int dst = slot_next[csch.blk[((size_t)r * P + p) * 2 + hh]];
+          hdG[((size_t)r * 2 + hh) * P + p] = (int64_t)dst * JB * mm;
+          hdV[((size_t)r * 2 + hh) * P + p] = (int64_t)dst * JB * nn;
+        }
+    }
   }
   hipError_t e;
   if ((e = hipMemcpyAsync(tabs, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
@@ -533,159 +597,93 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
   const int rounds = (P == 1) ? 1 : 2 * P - 1;
   unsigned long long hflag = 0;
   double mx_last = 0.0;
-  // Two streams: the V accumulation of round r (bandwidth-bound, needs only W_r) runs on s2 while the main
-  // stream already forms the Gram matrices / rotations of round r+1 (latency-bound, 1 workgroup per pair).
+  // Unchained order (NC == 1), two streams: the V accumulation of round r (bandwidth-bound, needs only W_r) runs on s2
+  // while the main stream already forms the Gram matrices / rotations of round r+1 (latency-bound, 1 workgroup per pair).
   // W is double-buffered; evW[b]: W_b written (s -> s2), evV[b]: W_b consumed by the V update (s2 -> s).
-  if (!s2) s2 = s;
-  hipEvent_t evW[2], evV[2];
-  for (int b = 0; b < 2; ++b) {
-    if ((e = hipEventCreateWithFlags(&evW[b], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&evV[b], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
-  }
-  hipEvent_t evPh[2] = {nullptr, nullptr}, evLag = nullptr;
-  if (phased) {
-    for (int b = 0; b < 2; ++b)
-      if ((e = hipEventCreateWithFlags(&evPh[b], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&evLag, hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) return e;
-  }
-  auto drop_events = [&]() {
-    for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(evW[b]); (void)hipEventDestroy(evV[b]); if (evPh[b]) (void)hipEventDestroy(evPh[b]); }
-    if (evLag) { (void)hipEventDestroy(evLag); evLag = nullptr; }
+  if (!s2 || vfree || NC > 1) s2 = s;
+  hipStream_t st[8] = {s, s, s, s, s, s, s, s};
+  for (int c = 1; c < NC; ++c) st[c] = xs[c - 1];
+  hipEvent_t evW[2], evV[2], evB[8], evLag[8];
+  std::vector<hipEvent_t> all_ev;
+  auto new_event = [&](hipEvent_t* ev) -> hipError_t {
+    hipError_t e2 = hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (e2 == hipSuccess) all_ev.push_back(*ev);
+    return e2;
   };
+  auto drop_events = [&]() { for (hipEvent_t ev : all_ev) (void)hipEventDestroy(ev); all_ev.clear(); };
+  for (int b = 0; b < 2; ++b) {
+    if ((e = new_event(&evW[b])) != hipSuccess) { drop_events(); return e; }
+    if ((e = new_event(&evV[b])) != hipSuccess) { drop_events(); return e; }
+  }
+  for (int c = 0; c < NC && NC > 1; ++c) {
+    if ((e = new_event(&evB[c])) != hipSuccess) { drop_events(); return e; }
+    if ((e = new_event(&evLag[c])) != hipSuccess) { drop_events(); return e; }
+  }
+  static const bool lag_on = !(getenv("MPSK_SVD_LAG") && atoi(getenv("MPSK_SVD_LAG")) == 0);
   long rc = 0;                              // global round counter
   int vcur = 0;
-  // V-free mode (mpsk_tsplit): nothing runs on s2, and the rotation kernel (latency-bound, one workgroup per pair) leaves
-  // most of the chip idle for ~100 us per round.  The round-robin order has LOCAL dependencies -- pair p of round r+1 is
-  // made of columns that sat in pairs p-1 / p+1 (or p itself at the two ends) in round r -- so the pairs are cut into NG
-  // contiguous groups, each on its own stream: a group starts round r+1 as soon as ITS neighbours have finished the
-  // update of round r (events, two sets by round parity), no barrier across all pairs.  Groups drift out of phase and
-  // the rotations of one group run under the Gram / update GEMMs of the others.  Ping-pong buffer hazards are covered
-  // by the same events (a group writes only slots of its own and its neighbours' pairs).
-  // MEASURED AND REJECTED as the default (MI355X, 4096^2 split, same 14 sweeps, identical results): 416 ms with one
-  // stream, 477 ms with 2 groups, 672 ms with 4 -- the cross-queue event waits (2 per group and round) and the 4x
-  // launch count cost more than the overlap returns.  Kept behind MPSK_SVD_GROUPS=2..4 for future runtimes.
-  int NG = 1;
-  hipStream_t gst[4] = {s, s, s, s};
-  hipEvent_t evU[2][4], evS = nullptr;
-  if (vfree && P >= 16) {
-    if (const char* ev = getenv("MPSK_SVD_GROUPS")) { NG = atoi(ev); if (NG < 1) NG = 1; if (NG > 4) NG = 4; }
-  }
-  if (NG > 1) {
-    static hipStream_t extra[3] = {nullptr, nullptr, nullptr};
-    for (int i = 0; i < NG - 1; ++i) {
-      if (!extra[i] && hipStreamCreateWithFlags(&extra[i], hipStreamNonBlocking) != hipSuccess) { NG = 1; break; }
-      gst[i + 1] = extra[i];
-    }
-  }
-  if (NG > 1) {
-    for (int b = 0; b < 2; ++b)
-      for (int g2 = 0; g2 < NG; ++g2)
-        if ((e = hipEventCreateWithFlags(&evU[b][g2], hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) { drop_events(); return e; }
-    if ((e = hipEventCreateWithFlags(&evS, hipEventDisableTiming | hipEventDisableSystemFence)) != hipSuccess) { drop_events(); return e; }
-  }
-  auto drop_group_events = [&]() {
-    if (NG > 1) {
-      for (int b = 0; b < 2; ++b) for (int g2 = 0; g2 < NG; ++g2) (void)hipEventDestroy(evU[b][g2]);
-      (void)hipEventDestroy(evS);
-    }
+  auto barrier_all = [&]() -> hipError_t {  // every chain has finished everything enqueued so far
+    hipError_t e2;
+    for (int c = 0; c < NC; ++c) if ((e2 = hipEventRecord(evB[c], st[c])) != hipSuccess) return e2;
+    for (int c = 0; c < NC; ++c)
+      for (int c2 = 0; c2 < NC; ++c2)
+        if (c2 != c && (e2 = hipStreamWaitEvent(st[c], evB[c2], 0)) != hipSuccess) return e2;
+    return hipSuccess;
   };
-  auto sync_groups = [&]() -> hipError_t {
-    for (int g2 = NG - 1; g2 >= 1; --g2) { hipError_t e2 = hipStreamSynchronize(gst[g2]); if (e2 != hipSuccess) return e2; }
+  auto sync_chains = [&]() -> hipError_t {
+    for (int c = NC - 1; c >= 1; --c) { hipError_t e2 = hipStreamSynchronize(st[c]); if (e2 != hipSuccess) return e2; }
     return hipSuccess;
   };
   for (int sweep = 0; sweep < 40; ++sweep) {
-    if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-    if (NG > 1) {
-      (void)hipEventRecord(evS, s);
-      for (int g2 = 1; g2 < NG; ++g2) (void)hipStreamWaitEvent(gst[g2], evS, 0);
-    }
-    if (phased) {
-      hipStream_t st[2] = {s, s_phase};
-      auto barrier = [&]() -> hipError_t {           // both halves have finished everything enqueued so far
-        hipError_t e2;
-        if ((e2 = hipEventRecord(evPh[0], st[0])) != hipSuccess) return e2;
-        if ((e2 = hipEventRecord(evPh[1], st[1])) != hipSuccess) return e2;
-        if ((e2 = hipStreamWaitEvent(st[0], evPh[1], 0)) != hipSuccess) return e2;
-        return hipStreamWaitEvent(st[1], evPh[0], 0);
-      };
-      auto half_round = [&](int inst, const int64_t* dest, double* Wb, hipEvent_t after_gram, hipEvent_t wait_first) -> hipError_t {
-        hipStream_t sg = st[inst];
-        const int p0 = inst * H, pn = H;
-        GemmArgs g;
-        std::memset(&g, 0, sizeof(g));
-        g.A = G[cur]; g.B = G[cur]; g.C = Mpart; g.M = J2; g.N = J2; g.lda = mm; g.ldb = mm; g.ldc = J2;
-        g.batch = pn * Q; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = 1; g.transB = 0;
-        g.tabA = t_gramA + (size_t)p0 * Q; g.tabB = g.tabA; g.tabC = t_gramC + (size_t)p0 * Q; g.tabs_even = kq_even;
-        g.K = kq;
-        hipError_t e2;
-        if (wait_first && (e2 = hipStreamWaitEvent(sg, wait_first, 0)) != hipSuccess) return e2;
-        if ((e2 = gemm_f64(g, sg)) != hipSuccess) return e2;
-        if (after_gram && (e2 = hipEventRecord(after_gram, sg)) != hipSuccess) return e2;
-        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(pn), dim3(256), 0, sg, Mpart + (size_t)p0 * Q * J2 * J2, Q,
-                           Wb + (size_t)p0 * J2 * J2, tol, flag, inner_sweeps);
-        GemmArgs u;
-        std::memset(&u, 0, sizeof(u));
-        u.B = Wb; u.N = J2; u.K = J2; u.ldb = J2; u.batch = pn; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
-        u.tabB = t_updB + p0; u.tabs_even = kq_even; u.splitN = JB;
-        u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G + p0;
-        u.tabC = dest + p0; u.tabC2 = dest + P + p0;
-        return gemm_f64(u, sg);
-      };
-      if ((e = barrier()) != hipSuccess) { drop_events(); drop_group_events(); return e; }      // (flag memset, previous sweep)
-      const int ph_rounds[3] = {2 * H - 1, H, H};
-      const int ph_norm[3] = {0, 2, 2}, ph_last[3] = {1, 3, 4};
-      for (int ph = 0; ph < 3; ++ph)
-        for (int r = 0; r < ph_rounds[ph]; ++r, ++rc) {
-          const bool last = (r == ph_rounds[ph] - 1);
-          double* Wb = Wm + (size_t)(rc & 1) * P * J2 * J2;
-          const int64_t* dest = t_phase + (size_t)(last ? ph_last[ph] : ph_norm[ph]) * 2 * P;
-          if (last && (e = barrier()) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-          // the two halves would march in lockstep (same durations, same start): half B starts a phase only when half A
-          // has finished its first Gram product, so that from then on B's GEMMs fall into A's rotation window and vice versa
-          const bool lag = (r == 0 && !last);
-          for (int inst = 0; inst < 2; ++inst)
-            if ((e = half_round(inst, dest, Wb, (lag && inst == 0) ? evLag : nullptr, (lag && inst == 1) ? evLag : nullptr)) != hipSuccess) {
-              drop_events(); drop_group_events(); return e;
-            }
-          if (last && (e = barrier()) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-          cur ^= 1;
-          vcur ^= 1;
-        }
-    }
-    for (int r = 0; r < (phased ? 0 : rounds); ++r, ++rc) {
-      const int wb = (int)(rc & 1);
-      double* Wb = Wm + (size_t)wb * P * J2 * J2;
-      if (NG > 1) {
-        const int eb = (int)(rc & 1), pb = eb ^ 1;
-        for (int g2 = 0; g2 < NG; ++g2) {
-          hipStream_t sg = gst[g2];
-          const int p0 = (int)((int64_t)P * g2 / NG), pn = (int)((int64_t)P * (g2 + 1) / NG) - p0;
-          if (rc > 0) {                       // neighbours' updates of the previous round
-            if (g2 > 0) (void)hipStreamWaitEvent(sg, evU[pb][g2 - 1], 0);
-            if (g2 < NG - 1) (void)hipStreamWaitEvent(sg, evU[pb][g2 + 1], 0);
-          }
+    if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) { drop_events(); return e; }
+    if (NC > 1) {
+      const int pc = csch.pc;
+      if ((e = barrier_all()) != hipSuccess) { drop_events(); return e; }      // (flag memset; the previous sweep's last round)
+      for (int r = 0; r < csch.rounds; ++r, ++rc) {
+        const bool last = csch.stage_last[r] != 0, first = csch.stage_first[r] != 0;
+        double* Wb = Wm + (size_t)(rc & 1) * P * J2 * J2;
+        const int64_t* dG = t_destG + (size_t)r * 2 * P;
+        const int64_t* dV = t_destV + (size_t)r * 2 * P;
+        if (last && (e = barrier_all()) != hipSuccess) { drop_events(); return e; }
+        // identical chains would march in lockstep (same durations, same start): at the start of a stage chain c starts
+        // only when chain c-1 has finished its first Gram product, so that from then on the GEMMs of one chain fall into
+        // the rotation windows of the others
+        const bool lag = lag_on && first && !last;
+        for (int c = 0; c < NC; ++c) {
+          hipStream_t sg = st[c];
+          const int p0 = c * pc;
+          if (lag && c > 0 && (e = hipStreamWaitEvent(sg, evLag[c - 1], 0)) != hipSuccess) { drop_events(); return e; }
           GemmArgs g;
           std::memset(&g, 0, sizeof(g));
           g.A = G[cur]; g.B = G[cur]; g.C = Mpart; g.M = J2; g.N = J2; g.lda = mm; g.ldb = mm; g.ldc = J2;
-          g.batch = pn * Q; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = 1; g.transB = 0;
+          g.batch = pc * Q; g.nseg = 1; g.alpha = 1.0; g.beta = 0.0; g.transA = 1; g.transB = 0;
           g.tabA = t_gramA + (size_t)p0 * Q; g.tabB = g.tabA; g.tabC = t_gramC + (size_t)p0 * Q; g.tabs_even = kq_even;
           g.K = kq;
-          if ((e = gemm_f64(g, sg)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-          hipLaunchKernelGGL(jacobi_eig_kernel, dim3(pn), dim3(256), 0, sg, Mpart + (size_t)p0 * Q * J2 * J2, Q,
+          if ((e = gemm_f64(g, sg)) != hipSuccess) { drop_events(); return e; }
+          if (lag && c + 1 < NC && (e = hipEventRecord(evLag[c], sg)) != hipSuccess) { drop_events(); return e; }
+          hipLaunchKernelGGL(jacobi_eig_kernel, dim3(pc), dim3(256), 0, sg, Mpart + (size_t)p0 * Q * J2 * J2, Q,
                              Wb + (size_t)p0 * J2 * J2, tol, flag, inner_sweeps);
           GemmArgs u;
           std::memset(&u, 0, sizeof(u));
-          u.B = Wb; u.N = J2; u.K = J2; u.ldb = J2; u.batch = pn; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
+          u.B = Wb; u.N = J2; u.K = J2; u.ldb = J2; u.batch = pc; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
           u.tabB = t_updB + p0; u.tabs_even = kq_even; u.splitN = JB;
-          u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G + p0; u.tabC = t_updC_G + p0;
-          u.tabC2 = t_updC_G + P + p0;
-          if ((e = gemm_f64(u, sg)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-          (void)hipEventRecord(evU[eb][g2], sg);
+          u.A = G[cur]; u.C = G[cur ^ 1]; u.M = mm; u.lda = mm; u.ldc = mm; u.tabA = t_updA_G + p0;
+          u.tabC = dG + p0; u.tabC2 = dG + P + p0;
+          if ((e = gemm_f64(u, sg)) != hipSuccess) { drop_events(); return e; }
+          if (!vfree) {
+            u.A = V[vcur]; u.C = V[vcur ^ 1]; u.M = nn; u.lda = nn; u.ldc = nn; u.tabA = t_updA_V + p0;
+            u.tabC = dV + p0; u.tabC2 = dV + P + p0;
+            if ((e = gemm_f64(u, sg)) != hipSuccess) { drop_events(); return e; }
+          }
         }
+        if (last && (e = barrier_all()) != hipSuccess) { drop_events(); return e; }
         cur ^= 1;
         vcur ^= 1;
-        continue;
       }
+    }
+    for (int r = 0; r < (NC > 1 ? 0 : rounds); ++r, ++rc) {
+      const int wb = (int)(rc & 1);
+      double* Wb = Wm + (size_t)wb * P * J2 * J2;
       // 1. Gram (TN): M[p][q] = X_p[rows of split q]^T X_p[rows of split q]
       GemmArgs g;
       std::memset(&g, 0, sizeof(g));
@@ -717,10 +715,9 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       vcur ^= 1;
     }
     ++sweeps;
-    if ((e = sync_groups()) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-    if (phased && (e = hipStreamSynchronize(s_phase)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-    if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) { drop_events(); drop_group_events(); return e; }
+    if ((e = sync_chains()) != hipSuccess) { drop_events(); return e; }
+    if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) { drop_events(); return e; }
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) { drop_events(); return e; }
     double mx;
     std::memcpy(&mx, &hflag, sizeof(double));
     if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] sweep %d: max |cos| = %.3e (tol %.1e)\n", sweeps, mx, tol);
@@ -734,7 +731,6 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     if ((e = hipStreamSynchronize(s2)) != hipSuccess) { drop_events(); return e; }
   }
   drop_events();
-  drop_group_events();
   if (sweeps_out) *sweeps_out = sweeps;
   if (!(mx_last <= 1.0e-9)) {               // 40 sweeps without reaching the quadratic regime: the factors would not be isometries
     if (err) {
@@ -744,7 +740,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     }
     return hipErrorNotReady;
   }
-  if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] %d x %d: P=%d Q=%d rounds/sweep=%d sweeps=%d\n", mm, nn, P, Q, rounds, sweeps);
+  if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] %d x %d: P=%d Q=%d rounds/sweep=%d sweeps=%d chains=%d\n", mm, nn, P, Q, rounds, sweeps, NC);
 
   // singular values, sorting, truncation (host)
   hipLaunchKernelGGL(colnorm2_kernel, dim3(npad), dim3(256), 0, s, G[cur], mm, mm, sigma2);

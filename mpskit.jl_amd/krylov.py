@@ -100,36 +100,61 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         out = be.empty(*shape)
         be.normalize_dev(ritz, out=out)
         return lam, out, fixed_matvecs, res
+    # Thick restart (Krylov-Schur for a Hermitian operator, what KrylovKit's eigsolve does with an Arnoldi / Lanczos
+    # factorization; the `keep` rule below is recalled from KrylovKit's source, which is not vendored in the reference:
+    # "parity unpinned", only the converged eigenpair is compared anywhere).  After krylovdim steps the basis is SHRUNK to
+    # the `keep` lowest Ritz vectors plus the residual direction instead of restarting from the Ritz vector alone:
+    #   A Y = Y diag(theta) + v_{m+1} b^T ,   b = beta_m S[m-1, :keep]
+    # is again an Arnoldi relation, so the expansion simply continues.  On the first to-tolerance sweep of the benchmark
+    # chain the single-vector restart needed 340 matvecs per site (profiles/r03_*), most of them re-learning directions
+    # the restart had thrown away.
+    m = int(min(krylovdim, max(x0.size, 1)))
+    nrm = be.norm(start)
+    be.axpby(1.0 / nrm, start, 0.0, V[0])
+    basis = list(V[:m + 1])                     # basis[i] = i-th Krylov vector; the remaining pool entries are scratch
+    spare = None
+    Hm = np.zeros((m + 1, m))
+    k, conv = 0, False
+    sv = None
     for _restart in range(maxiter):
-        nrm = be.norm(start)
-        be.axpby(1.0 / nrm, start, 0.0, V[0])
-        Hm = np.zeros((krylovdim + 1, krylovdim))
-        k, conv = 0, False
-        s = None
-        while k < krylovdim:
-            w = V[k + 1]
-            matvec(V[k], w)
+        while k < m:
+            w = basis[k + 1]
+            matvec(basis[k], w)
             if nmv == 0 and first_image is not None:
                 be.axpby(1.0, w, 0.0, first_image)
             nmv += 1
-            h, beta = be.orth_step(V[:k + 1], w)      # CGS2 + normalise, one host sync
+            h, beta = be.orth_step(basis[:k + 1], w)      # CGS2 + normalise, one host sync
             Hm[:k + 1, k] = h
             Hm[k + 1, k] = beta
             k += 1
             Hk = Hm[:k, :k]
             ev, S = np.linalg.eigh((Hk + Hk.T) / 2)
-            lam, s = ev[0], S[:, 0]
-            res = abs(beta * s[-1])
+            lam, sv = ev[0], S[:, 0]
+            res = abs(Hm[k, :k] @ sv)                     # |(last row of the (k+1) x k matrix) . s| = Ritz residual norm
             done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
             # breakdown: the Krylov space is invariant (always the case once k reaches the vector-space dimension)
             breakdown = beta <= 1e-13 * max(np.abs(Hk).max(), 1e-300) or k >= x0.size
             if (fixed_matvecs is None and res < tol) or breakdown or done_fixed:
                 conv = True
                 break
-        be.lincomb(V[:k], s, out=ritz)
-        start = ritz
-        if conv:
+        if conv or _restart == maxiter - 1:
             break
+        # shrink: keep the lowest Ritz vectors (KrylovKit: keep = div(3 krylovdim + 2 converged, 5), converged = 0 here)
+        keep = max(1, min(m - 1, (3 * m) // 5))
+        if spare is None:
+            spare = ws.get(shape, keep, tag="thick-restart")
+        for j in range(keep):
+            be.lincomb(basis[:m], S[:, j], out=spare[j])
+        resid = basis[m]                                  # v_{m+1}
+        coupling = Hm[m, m - 1] * S[m - 1, :keep]
+        old = basis[:m]
+        basis = list(spare[:keep]) + [resid] + old[:m - keep]      # m + 1 vectors again
+        spare = old[m - keep:m]                                       # the other `keep` old vectors: next shrink's targets
+        Hm = np.zeros((m + 1, m))
+        Hm[:keep, :keep] = np.diag(ev[:keep])
+        Hm[keep, :keep] = coupling
+        k = keep
+    be.lincomb(basis[:k], sv, out=ritz)
     out = be.empty(*shape)
     nrm = be.norm(ritz)
     if nrm == 0.0:
