@@ -82,8 +82,15 @@ int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallba
 int mpsk_ctx_qr_retries(mpsk_ctx* ctx, long* n_retry);
 /* tsvd algorithm switch: 0 = Jacobi on theta directly; 1 = the tall orientation of theta is factored with QRpos first and
  * the block-Jacobi iteration runs on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra); 2 (default)
- * = additionally R^T = Q1 R1 and the iteration runs on R1^T (mpsk_tsplit only: 15 -> 10 sweeps on graded 4096^2 tensors;
- * mpsk_tsvd treats 2 as 1).  mpsk_ctx_svd_stats returns the number of Jacobi sweeps of the last mpsk_tsvd / mpsk_tsplit. */
+ * = additionally R^T = Q1 R1 and the iteration runs on R1^T (V-free in mpsk_tsplit, with accumulated rotations in
+ * mpsk_tsvd: 15 -> 10 sweeps on graded 4096^2 tensors for one more n x n QRpos).  mpsk_ctx_svd_stats returns the number of
+ * Jacobi sweeps of the last mpsk_tsvd / mpsk_tsplit.
+ * Mode 0 has no relative accuracy on matrices whose COLUMNS are nearly parallel (condition number of the column-scaled
+ * matrix >= 1/u, e.g. U diag(logspace(0,-14)) V^T behind random orthogonal factors): every rotation against an O(1) column
+ * injects rounding noise u |a_big| into columns whose norm is of that order, so their mutual cosines stay O(1) and the
+ * scale-invariant convergence test cannot be met; the call then returns MPSK_ERR_HIP "did not converge" instead of
+ * non-isometric factors.  (Demmel-Veselic: one-sided Jacobi is accurate for A = B D with B well conditioned -- which is
+ * what the QR preconditioning of modes 1 / 2 produces.) */
 int mpsk_ctx_set_svd_mode(mpsk_ctx* ctx, int precondition);
 int mpsk_ctx_svd_stats(mpsk_ctx* ctx, int* last_sweeps);
 /* tile override for benchmarking the GEMM core (0,0 restores the heuristic) */

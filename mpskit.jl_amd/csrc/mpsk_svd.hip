@@ -14,12 +14,14 @@
 // which a Gram-matrix eigensolve of the whole theta would not.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <utility>
 #include <vector>
 #include "mpsk_internal.h"
 
@@ -314,6 +316,379 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
   }
 }
 
+// ---- rotation kernel, second generation (MPSK_SVD_EIG=1 selects the first) -------------------------------------------
+// Same mathematics as jacobi_eig_kernel (scaled Cholesky of the pair's Gram matrix, one-sided cyclic Jacobi on the factor R,
+// accumulated rotations W, one Newton-Schulz step), different data placement.  The first kernel keeps R AND W in LDS and every
+// one of the 63 steps reads and writes both (128 KB of LDS traffic per step, ~770 cycles of ds_write alone): 70 of its
+// ~100 us.  Here W never touches LDS during the iteration:
+//   * waves 0-3 rotate R in LDS exactly as before (8 lanes per column pair) and publish each pair's (c, s);
+//   * wave 4 holds W in REGISTERS, lane = row, 64 columns = 64 register pairs.  The round-robin order is known at compile
+//     time, so with the 63 steps fully unrolled every rotation addresses its two columns statically; the wave applies the
+//     rotations of step t while the other four work on step t + 1 (one barrier per step, (c, s) double-buffered).
+// LDS traffic per step halves and W's rotations leave the critical path.
+constexpr int EIG2_THREADS = 320;
+
+__host__ __device__ constexpr int eig2_lo(int t, int pk) {
+  const int a = (pk == 0) ? J2 - 1 : (t + pk) % (J2 - 1), b = (pk == 0) ? t : (t + (J2 - 1) - pk) % (J2 - 1);
+  return a < b ? a : b;
+}
+__host__ __device__ constexpr int eig2_hi(int t, int pk) {
+  const int a = (pk == 0) ? J2 - 1 : (t + pk) % (J2 - 1), b = (pk == 0) ? t : (t + (J2 - 1) - pk) % (J2 - 1);
+  return a < b ? b : a;
+}
+// wave 4: the 32 rotations of step T on the register-resident rows of W (every index a compile-time constant).  The
+// (c, s) pairs are broadcast LDS reads (all lanes, one address), fetched in groups of 8 one group ahead of their use;
+// scheduling barriers keep the compiler from clustering all 32 reads up front (128 more live registers: it spilled W).
+typedef double sv_d2 __attribute__((ext_vector_type(2)));
+template <int T, int G, int... K>
+__device__ __forceinline__ void eig2_w_group(double (&w)[J2], const sv_d2 (&cb)[8], std::integer_sequence<int, K...>) {
+  ((void)([&] {
+     constexpr int pp = eig2_lo(T, 8 * G + K), qq = eig2_hi(T, 8 * G + K);
+     const double c = cb[K].x, sn = cb[K].y;
+     const double a = w[pp], b = w[qq];
+     w[pp] = c * a - sn * b;
+     w[qq] = sn * a + c * b;
+     // pins the rotation HERE: pure arithmetic is not ordered against s_barrier, and without this the compiler sank all
+     // 2016 rotations behind the last barrier and spilled every (c, s) it had to read in place (32 KB of scratch per lane)
+     asm volatile("" : "+v"(w[pp]), "+v"(w[qq]));
+   }()),
+   ...);
+}
+template <int G>
+__device__ __forceinline__ void eig2_w_fetch(sv_d2 (&cb)[8], const double* __restrict__ csb) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cb[k] = *reinterpret_cast<const sv_d2*>(csb + 2 * (8 * G + k));
+}
+template <int T>
+__device__ __forceinline__ void eig2_w_apply(double (&w)[J2], const double* __restrict__ csb) {
+  sv_d2 c0[8], c1[8];
+  constexpr auto seq = std::make_integer_sequence<int, 8>{};
+  eig2_w_fetch<0>(c0, csb);
+  eig2_w_fetch<1>(c1, csb);
+  __builtin_amdgcn_sched_barrier(0);
+  eig2_w_group<T, 0>(w, c0, seq);
+  __builtin_amdgcn_sched_barrier(0);
+  eig2_w_fetch<2>(c0, csb);
+  __builtin_amdgcn_sched_barrier(0);
+  eig2_w_group<T, 1>(w, c1, seq);
+  __builtin_amdgcn_sched_barrier(0);
+  eig2_w_fetch<3>(c1, csb);
+  __builtin_amdgcn_sched_barrier(0);
+  eig2_w_group<T, 2>(w, c0, seq);
+  __builtin_amdgcn_sched_barrier(0);
+  eig2_w_group<T, 3>(w, c1, seq);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// waves 0-3: step `st` of the one-sided Jacobi sweep on R (LDS) for the pair of this 8-lane team; publishes (c, s)
+__device__ __forceinline__ void eig2_r_step(double (*Ms)[J2 + 1], double* __restrict__ csw, int st, int pk, int pj, int* rotated) {
+  const int pp = eig2_lo(st, pk), qq = eig2_hi(st, pk);
+  double rp[8], rq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = pj + 8 * i;
+    rp[i] = Ms[r][pp]; rq[i] = Ms[r][qq];
+  }
+  double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { al += rp[i] * rp[i]; be += rq[i] * rq[i]; ga += rp[i] * rq[i]; }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
+  }
+  // rotation parameters: see jacobi_eig_kernel (fp32 tangent, fp64-polished cosine)
+  double c = 1.0, sn = 0.0;
+  const double ab = al * be, gg = ga * ga;
+  if (gg > 1.0e-34 * ab) {
+    const double num = (be - al) * 0.5;
+    int ex;
+    (void)frexp(fmax(fabs(num), fabs(ga)), &ex);
+    const float zf = (float)ldexp(num, -ex) * __frcp_rn((float)ldexp(ga, -ex));
+    const float az = fabsf(zf);
+    const float tf = copysignf(1.0f, zf) * (az > 1.0e4f ? 0.5f * __frcp_rn(az) : __frcp_rn(az + __fsqrt_rn(1.0f + zf * zf)));
+    const double t = (double)tf;
+    const double x = 1.0 + t * t;
+    double r = (double)__frsqrt_rn((float)x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    c = r;
+    sn = r * t;
+    if (gg > 1.0e-20 * ab) *rotated = 1;
+  }
+  if (pj == 0) { csw[2 * pk] = c; csw[2 * pk + 1] = sn; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = pj + 8 * i;
+    Ms[r][pp] = c * rp[i] - sn * rq[i];
+    Ms[r][qq] = sn * rp[i] + c * rq[i];
+  }
+}
+
+// wave 4's side of one inner sweep: phase ST applies the rotations of step ST - 1 (published by waves 0-3 during phase
+// ST - 1) and joins the phase's barrier.  Waves 0-3 run their own, rolled loop with the SAME number of barriers
+// (s_barrier counts arrivals, not program locations).
+template <int ST>
+__device__ __forceinline__ void eig2_w_phases(double (*cs)[2 * 32], double (&w)[J2]) {
+  if constexpr (ST < J2) {
+    if constexpr (ST >= 1) eig2_w_apply<ST - 1>(w, cs[(ST - 1) & 1]);
+    __syncthreads();
+    eig2_w_phases<ST + 1>(cs, w);
+  }
+}
+
+__global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double* __restrict__ Mpart, int Q,
+                                                                   double* __restrict__ Wout, double tol,
+                                                                   unsigned long long* __restrict__ flag, int inner_sweeps,
+                                                                   unsigned long long* __restrict__ dbg) {
+  __shared__ double Ms[J2][J2 + 1];
+  __shared__ double Ws[J2][J2 + 1];
+  __shared__ double P[2][4][J2];
+  __shared__ double dsc[J2], dinv[J2];
+  __shared__ __attribute__((aligned(16))) double cs[2][2 * 32];     // (c, s) of pair k of a step at [buf][2k], [2k + 1]
+  __shared__ double red[4];
+  __shared__ int any_rot;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool rw = tid < 256;                 // waves 0-3: everything the first kernel's 256 threads did, except W
+  const int p = blockIdx.x;
+  const double* Mp = Mpart + (size_t)p * Q * J2 * J2;
+  // diagnostic stamps (dbg != nullptr only in profiling runs: MPSK_SVD_STAMPS=1), 100 MHz real-time counter
+#define EIG2_STAMP(i) do { if (dbg && tid == 0 && p == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  EIG2_STAMP(0);
+  if (rw) {
+    double accv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accv[i] = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < Q; ++q) {
+      const double* mq = Mp + (size_t)q * J2 * J2 + tid;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accv[i] += mq[256 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i;
+      Ms[e % J2][e / J2] = accv[i];
+    }
+  }
+  __syncthreads();
+  EIG2_STAMP(1);
+  double mx = 0.0;
+  if (rw) {
+    for (int e = tid; e < J2 * J2; e += 256) {
+      const int i = e % J2, j = e / J2;
+      if (i < j) {
+        const double a = 0.5 * (Ms[i][j] + Ms[j][i]);
+        const double dd = Ms[i][i] * Ms[j][j];
+        const double r = (a == 0.0) ? 0.0 : (dd > 0.0 ? fabs(a) / sqrt(dd) : 1.0);
+        mx = fmax(mx, r);
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+  }
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (tid == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(mx));
+  double* Wp = Wout + (size_t)p * J2 * J2;
+  if (mx <= tol) {                           // (uniform over the workgroup)
+    for (int e = tid; e < J2 * J2; e += EIG2_THREADS) Wp[e] = (e % J2 == e / J2) ? 1.0 : 0.0;
+    return;
+  }
+  __syncthreads();
+  if (rw)
+    for (int e = tid; e < J2 * J2; e += 256) {
+      const int i = e % J2, j = e / J2;
+      if (i < j) { const double a = 0.5 * (Ms[i][j] + Ms[j][i]); Ms[i][j] = a; }
+    }
+  __syncthreads();
+  if (rw)
+    for (int e = tid; e < J2 * J2; e += 256) {
+      const int i = e % J2, j = e / J2;
+      if (i > j) Ms[i][j] = Ms[j][i];
+    }
+  __syncthreads();
+  EIG2_STAMP(2);
+  // ---- (1) Cholesky of the unit-diagonal scaled Gram matrix, rows four at a time (see jacobi_eig_kernel)
+  const int wr = (wave >> 1) & 1, wc = wave & 1, lr = lane >> 4, lc = lane & 15;
+  if (tid < J2) {
+    const double dd = Ms[tid][tid];
+    dsc[tid] = dd > 0.0 ? sqrt(dd) : 0.0;
+    dinv[tid] = dd > 0.0 ? 1.0 / sqrt(dd) : 0.0;
+  }
+  __syncthreads();
+  sv_d4 acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = sv_d4{0.0, 0.0, 0.0, 0.0};
+  if (rw) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int rr = 32 * wr + 16 * ti + lr + 4 * rg, cc = 32 * wc + 16 * tj + lc;
+          acc[ti][tj][rg] = (rr == cc) ? (dinv[rr] > 0.0 ? 1.0 : 0.0) : Ms[rr][cc] * dinv[rr] * dinv[cc];
+        }
+  }
+  const double ptol = 1.0e-14;
+  __syncthreads();                           // everyone has read Ms before it is overwritten with R
+  for (int c = 0; c < J2 / 4; ++c) {
+    const int j0 = 4 * c;
+    double (*Pb)[J2] = P[c & 1];
+    if (rw && wr == (j0 >> 5)) {
+      const int ti = (j0 >> 4) & 1, q = (j0 >> 2) & 3;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const sv_d4 v = ti ? acc[1][tj] : acc[0][tj];
+        Pb[lr][32 * wc + 16 * tj + lc] = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double pr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pr[t] = Pb[t][lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double piv = sv_readlane(pr[t], j0 + t);
+        const bool ok = (piv > ptol) && (piv < 1.0e300);     // semi-definite: a vanishing pivot zeroes the row
+        double rs_, sq_;
+        sv_piv_rsqrt(ok ? piv : 1.0, &rs_, &sq_);
+        const double sq = ok ? sq_ : 0.0;
+        const double rs = ok ? rs_ : 0.0;
+        pr[t] = (lane > j0 + t) ? pr[t] * rs : (lane == j0 + t ? sq : 0.0);
+#pragma unroll
+        for (int u = t + 1; u < 4; ++u) pr[u] -= sv_readlane(pr[t], j0 + u) * pr[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { Pb[t][lane] = pr[t]; Ms[j0 + t][lane] = pr[t] * dsc[lane]; }   // row j0+t of R = R~ D
+    }
+    __syncthreads();
+    if (rw) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) af[ti] = -Pb[lr][32 * wr + 16 * ti + lc];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) bf[tj] = Pb[lr][32 * wc + 16 * tj + lc];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  EIG2_STAMP(3);
+  // ---- (2) one-sided Jacobi on R (LDS, waves 0-3); W in the registers of wave 4.  The two sides run DIFFERENT code with
+  // the same barrier count per inner sweep: 1 + 64 + 1 (+ 1 when another sweep follows), then one before step (3).
+  if (rw) {
+    const int team = tid >> 3, pj = tid & 7;
+    const int pk = ((team & 3) << 3) | (team >> 2);
+    for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
+      if (tid == 0) any_rot = 0;
+      __syncthreads();
+      int rotated = 0;
+      for (int st = 0; st < J2; ++st) {      // phase st: step st (< 63); wave 4 applies step st - 1 meanwhile
+        if (st < J2 - 1) eig2_r_step(Ms, cs[st & 1], st, pk, pj, &rotated);
+        __syncthreads();
+      }
+      if (rotated) any_rot = 1;
+      __syncthreads();
+      if (!any_rot) break;
+      __syncthreads();
+    }
+    __syncthreads();
+  } else {
+    double w[J2];
+#pragma unroll
+    for (int c = 0; c < J2; ++c) w[c] = (c == lane) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
+      __syncthreads();
+      eig2_w_phases<0>(cs, w);
+      __syncthreads();
+      if (!any_rot) break;
+      __syncthreads();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < J2; ++c) Ws[lane][c] = w[c];
+  }
+  // ---- (3) Newton-Schulz step  W <- W (3 I - W^T W) / 2  on the matrix cores (waves 0-3)
+  __syncthreads();
+  EIG2_STAMP(4);
+  {
+    const int fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = sv_d4{0.0, 0.0, 0.0, 0.0};
+    if (rw) {
+      for (int k0 = 0; k0 < J2; k0 += 4) {       // T = W^T W
+        double af[2], bf[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) af[ti] = Ws[k0 + fq][32 * wr + 16 * ti + fr];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) bf[tj] = Ws[k0 + fq][32 * wc + 16 * tj + fr];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) Ms[32 * wr + 16 * ti + fq + 4 * rg][32 * wc + 16 * tj + fr] = acc[ti][tj][rg];
+    }
+    __syncthreads();
+    if (rw) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = sv_d4{0.0, 0.0, 0.0, 0.0};
+      for (int k0 = 0; k0 < J2; k0 += 4) {       // P = W T
+        double af[2], bf[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) af[ti] = Ws[32 * wr + 16 * ti + fr][k0 + fq];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) bf[tj] = Ms[k0 + fq][32 * wc + 16 * tj + fr];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int i = 32 * wr + 16 * ti + fq + 4 * rg, j = 32 * wc + 16 * tj + fr;
+            Wp[i + J2 * j] = 1.5 * Ws[i][j] - 0.5 * acc[ti][tj][rg];
+          }
+    }
+  }
+  EIG2_STAMP(5);
+#undef EIG2_STAMP
+}
+
+// MPSK_SVD_STAMPS=1: pair 0 of every launch leaves six real-time stamps (100 MHz) here; printed with MPSK_SVD_DEBUG
+static unsigned long long* g_eig2_dbg = nullptr;
+static const int g_svd_eig = getenv("MPSK_SVD_EIG") ? atoi(getenv("MPSK_SVD_EIG")) : 2;
+static inline void launch_eig(int npairs, hipStream_t s, const double* Mpart, int Q, double* Wb, double tol,
+                              unsigned long long* flag, int inner_sweeps) {
+  if (g_svd_eig == 1)
+    hipLaunchKernelGGL(jacobi_eig_kernel, dim3(npairs), dim3(256), 0, s, Mpart, Q, Wb, tol, flag, inner_sweeps);
+  else
+    hipLaunchKernelGGL(jacobi_eig2_kernel, dim3(npairs), dim3(EIG2_THREADS), 0, s, Mpart, Q, Wb, tol, flag, inner_sweeps, g_eig2_dbg);
+}
+
 // sigma2[j] = sum_r G[r, j]^2   (one workgroup per column)
 __global__ __launch_bounds__(256) void colnorm2_kernel(const double* __restrict__ G, int ldg, int m,
                                                        double* __restrict__ sigma2) {
@@ -446,7 +821,10 @@ static bool build_chain_schedule(int P, int NC, ChainSched* sc) {
 }
 
 static int svd_default_chains(int P) {
-  int nc = (P >= 32 && P % 4 == 0) ? 4 : ((P >= 16 && P % 2 == 0) ? 2 : 1);
+  // measured (MI355X, mode 2, graded6; profiles/r03_svd_chains.log): n = 1024 (P = 16): 27.3 ms unchained, 34.0 with 2 chains
+  // (the stage barriers cost more than the overlap returns on launches this small); n = 2048: 86 / 84 / 92 ms with 1 / 2 / 4;
+  // n = 4096: 290 / - / 252 ms
+  int nc = (P >= 64 && P % 4 == 0) ? 4 : ((P >= 32 && P % 2 == 0) ? 2 : 1);
   if (const char* ev = getenv("MPSK_SVD_CHAINS")) { const int v = atoi(ev); if (v >= 1 && v <= 8) nc = v; }
   if (nc > 1 && (P % nc != 0 || P / nc < 2)) nc = 1;
   return nc;
@@ -581,6 +959,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     }
   }
   hipError_t e;
+  if (!g_eig2_dbg && getenv("MPSK_SVD_STAMPS")) { if (hipMalloc(&g_eig2_dbg, 64) != hipSuccess) g_eig2_dbg = nullptr; }
   if ((e = hipMemcpyAsync(tabs, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(svd_init_kernel, dim3(2048), dim3(256), 0, s, theta, ldt, m, n, pl.transposed, G[0], mm, npad,
                      V[0], nn);
@@ -635,6 +1014,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     return hipSuccess;
   };
   for (int sweep = 0; sweep < 40; ++sweep) {
+    const auto t_sweep0 = std::chrono::steady_clock::now();
     if ((e = hipMemsetAsync(flag, 0, sizeof(unsigned long long), s)) != hipSuccess) { drop_events(); return e; }
     if (NC > 1) {
       const int pc = csch.pc;
@@ -661,8 +1041,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
           g.K = kq;
           if ((e = gemm_f64(g, sg)) != hipSuccess) { drop_events(); return e; }
           if (lag && c + 1 < NC && (e = hipEventRecord(evLag[c], sg)) != hipSuccess) { drop_events(); return e; }
-          hipLaunchKernelGGL(jacobi_eig_kernel, dim3(pc), dim3(256), 0, sg, Mpart + (size_t)p0 * Q * J2 * J2, Q,
-                             Wb + (size_t)p0 * J2 * J2, tol, flag, inner_sweeps);
+          launch_eig(pc, sg, Mpart + (size_t)p0 * Q * J2 * J2, Q, Wb + (size_t)p0 * J2 * J2, tol, flag, inner_sweeps);
           GemmArgs u;
           std::memset(&u, 0, sizeof(u));
           u.B = Wb; u.N = J2; u.K = J2; u.ldb = J2; u.batch = pc; u.nseg = 1; u.alpha = 1.0; u.beta = 0.0;
@@ -694,7 +1073,7 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       if ((e = gemm_f64(g, s)) != hipSuccess) { drop_events(); return e; }
       // 2. rotations of each 64-column pair (W_b may still be read by the V update of round rc - 2)
       if (rc >= 2 && s2 != s) (void)hipStreamWaitEvent(s, evV[wb], 0);
-      hipLaunchKernelGGL(jacobi_eig_kernel, dim3(P), dim3(256), 0, s, Mpart, Q, Wb, tol, flag, inner_sweeps);
+      launch_eig(P, s, Mpart, Q, Wb, tol, flag, inner_sweeps);
       if (s2 != s) (void)hipEventRecord(evW[wb], s);
       // 3. updates into next round's slots: G on the main stream, V on s2
       GemmArgs u;
@@ -715,12 +1094,22 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
       vcur ^= 1;
     }
     ++sweeps;
+    const auto t_enq = std::chrono::steady_clock::now();
     if ((e = sync_chains()) != hipSuccess) { drop_events(); return e; }
     if ((e = hipMemcpyAsync(&hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, s)) != hipSuccess) { drop_events(); return e; }
     if ((e = hipStreamSynchronize(s)) != hipSuccess) { drop_events(); return e; }
     double mx;
     std::memcpy(&mx, &hflag, sizeof(double));
-    if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] sweep %d: max |cos| = %.3e (tol %.1e)\n", sweeps, mx, tol);
+    if (getenv("MPSK_SVD_DEBUG")) {
+      const auto t_done = std::chrono::steady_clock::now();
+      fprintf(stderr, "[mpsk_tsvd] sweep %d: max |cos| = %.3e (tol %.1e)  host enqueue %.2f ms, sweep %.2f ms\n", sweeps, mx, tol,
+              std::chrono::duration<double, std::milli>(t_enq - t_sweep0).count(),
+              std::chrono::duration<double, std::milli>(t_done - t_sweep0).count());
+      unsigned long long hs[6];
+      if (g_eig2_dbg && sweeps <= 2 && hipMemcpy(hs, g_eig2_dbg, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf(stderr, "[mpsk_tsvd] eig2 stamps, pair 0 of the sweep's last launch (us): load %.2f  measure+symm %.2f  cholesky %.2f  jacobi %.2f  newton-schulz %.2f\n",
+                (hs[1] - hs[0]) * 0.01, (hs[2] - hs[1]) * 0.01, (hs[3] - hs[2]) * 0.01, (hs[4] - hs[3]) * 0.01, (hs[5] - hs[4]) * 0.01);
+    }
     mx_last = mx;
     if (mx <= tol) break;
     // Quadratic convergence: a sweep that STARTED with every |cos| <= 1e-9 leaves them at the rounding floor,
@@ -741,7 +1130,6 @@ hipError_t tsvd(int m, int n, const double* theta, int ldt, double* U, int ldu, 
     return hipErrorNotReady;
   }
   if (getenv("MPSK_SVD_DEBUG")) fprintf(stderr, "[mpsk_tsvd] %d x %d: P=%d Q=%d rounds/sweep=%d sweeps=%d chains=%d\n", mm, nn, P, Q, rounds, sweeps, NC);
-
   // singular values, sorting, truncation (host)
   hipLaunchKernelGGL(colnorm2_kernel, dim3(npad), dim3(256), 0, s, G[cur], mm, mm, sigma2);
   std::vector<double> hs(npad);

@@ -393,8 +393,12 @@ def test_tsvd_graded_and_rank_deficient_preconditioned(be):
     from mpskit_jl_amd._lib import MpskError
     try:
         be.set_svd_mode(False)
-        # plain block Jacobi stalls on graded input: after the 40-sweep cap the factors would not be isometries, and the
-        # library says so instead of returning them (mpsk.h: "did not converge")
+        # plain block Jacobi cannot converge on this input, for a mathematical reason (include/mpsk.h, svd mode 0): the
+        # columns of A are nearly parallel (cond of the column-scaled matrix 1e14 ~ 1/u); each rotation against an O(1)
+        # column injects noise u |a_big| ~ 1e-16 into columns whose norm IS 1e-14..1e-16, so their mutual cosines stay
+        # O(1) (measured: max |cos| = 0.41 after 40 sweeps) and the scale-invariant test never passes.  The library
+        # says so instead of returning non-isometries (mpsk.h: "did not converge"); modes 1 / 2 iterate on R^T = B D with
+        # B well conditioned (Demmel-Veselic), where the same 14-decade spectrum converges in <= 12 sweeps.
         with pytest.raises(MpskError, match="did not converge"):
             be.tsvd(be.upload(A), max_keep=128)
         sw_plain = be.svd_sweeps()
