@@ -7,14 +7,17 @@ is block-partitioned over the P ranks.  What lives where (D = bond dimension, n 
   left environments   permanently ROW-sharded: rank p stores GL[w][a'_p, :]  (W, n, D)        -> 1/P of the memory
   right environments  stored COLUMN-sharded over the bra index: GR[w][:, a'_p]  (W, D, n)     -> 1/P of the memory;
                       a full copy is all-gathered ONCE PER SITE VISIT (stage 3 of the matvec reads all of GR) into a
-                      transient buffer (at most two alive)
+                      transient buffer (at most two alive): ONE collective into the rank-major layout [P][W][D][n], then P
+                      strided device copies into the slab layout [W][D][D]
   Krylov vectors      replicated, in the BLOCKED layout [P][n, d, D] (rank blocks back to back): the local matvec
                       (mpsk_dAC_blocked: the blocks are K-segments of the stage-1 GEMM) writes this rank's block
                       straight into the destination vector and ONE in-place all-gather completes it -- no per-matvec
                       allocation, no re-interleave kernels; vector arithmetic (dots, axpys, Gram-Schmidt) is layout
                       agnostic.  A tensor is converted rows <-> blocks once per site visit (encode / decode).
-  environment update  transfer_left : all three stages on the local rows, the partial result (contraction over the
-                      sharded a') completed by ONE all-reduce, every rank keeps its rows;
+  environment update  transfer_left : all three stages on the local rows; the partial result (contraction over the
+                      sharded a') is re-ordered into rank-major row blocks [P][W][n][D] (one device copy) and completed
+                      by ONE reduce-scatter -- every rank receives exactly the rows it stores, half the traffic of the
+                      all-reduce + slice of round 2 (an all-reduce remains where the output bond is too small to shard);
                       transfer_right: rank p computes the bra columns a'_p from the gathered input -- no reduction.
   gauge steps (QRpos / LQpos), state tensors: replicated ("replicas only" for those steps).
 
@@ -66,8 +69,8 @@ class Comm:
         one-GPU box; needs an initialised process group)."""
         self.world, self.rank, self.group, self.staged = int(world), int(rank), group, staged
         self.force_collective = force_collective
-        self.n_allgather = self.n_allreduce = 0
-        self.bytes_allgather = self.bytes_allreduce = 0
+        self.n_allgather = self.n_allreduce = self.n_reduce_scatter = 0
+        self.bytes_allgather = self.bytes_allreduce = self.bytes_reduce_scatter = 0
         self._inplace = None
 
     def _dist(self):
@@ -112,6 +115,25 @@ class Comm:
             return buf
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return buf
+
+    def reduce_scatter_sum(self, out, inp):
+        """out = sum over ranks of chunk `rank` of inp (inp = world equal contiguous chunks of out.numel() elements).
+        RCCL: ncclReduceScatter; gloo has no reduce-scatter (CPU tests / host-staged ranks): all-reduce + slice there --
+        the byte count recorded is what the RCCL path moves."""
+        self.n_reduce_scatter += 1
+        self.bytes_reduce_scatter += inp.numel() * 8
+        n = out.numel()
+        if self.world == 1 and not self.force_collective:
+            out.copy_(inp[:n])
+            return out
+        dist = self._dist()
+        if self.staged or dist.get_backend(self.group) != "nccl":
+            h = inp.cpu() if self.staged else inp.clone()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(h[self.rank * n:(self.rank + 1) * n].to(out.device))
+            return out
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
+        return out
 
     def all_reduce_scalar(self, v):
         import torch
@@ -314,11 +336,20 @@ class ShardedFinEnv:
         lo, hi = self._lohi(Dl)
         abloc = rows_of_tensor(be, al, lo, hi)
         part = be.transfer_left(Hs, GLin, al, abloc)               # contraction over the local rows a'_p only
-        self.comm.all_reduce_sum(part.buf[:part.size])
         if kout == "rep":
+            self.comm.all_reduce_sum(part.buf[:part.size])
             return part, kout
-        lo, hi = self._lohi(Dr)
-        return rows_of_env(be, part, lo, hi), kout
+        # row-sharded output: rank q needs rows q of every slab -> rank-major row blocks [P][W][n, Dr] (rows q of all slabs
+        # = one (n x W Dr) sub-matrix of the (Drb x W Dr) matrix `part`), then ONE reduce-scatter: half the bytes of an
+        # all-reduce, and nothing is received that is thrown away
+        W, Drb, Drk = part.shape
+        P, n2 = self.P, Drb // self.P
+        blocks = be.empty(P, W, n2, Drk)
+        for q in range(P):
+            be.copy2d(n2, W * Drk, part.ptr + 8 * q * n2, Drb, blocks.ptr + 8 * q * W * n2 * Drk, n2)
+        out = be.empty(W, n2, Drk)
+        self.comm.reduce_scatter_sum(out.buf[:out.size], blocks.buf[:blocks.size])
+        return out, kout
 
     def _gathered_right(self, idx):
         """full (W, Dk, Db) copy of right environment `idx` (the bond index), gathered if stored column-sharded."""
@@ -329,10 +360,15 @@ class ShardedFinEnv:
         if hit is not None and hit[0] is t:
             return hit[1]
         W, Dk, n = t.shape
-        full = self.be.empty(W, Dk, n * self.P)
+        be, P = self.be, self.P
+        full = be.empty(W, Dk, n * P)
         slab = Dk * n
-        for w in range(W):      # slab w of the full tensor = the ranks' column blocks back to back
-            self.comm.all_gather_into(full.buf[w * slab * self.P:(w + 1) * slab * self.P], t.buf[w * slab:(w + 1) * slab])
+        # ONE collective (rank-major [P][W][Dk, n]), then P strided device copies: rank q's column block of every slab is
+        # one chunk of Dk n contiguous elements per slab (round 2 issued W collectives per gather)
+        staged = be.empty(P, W, Dk, n)
+        self.comm.all_gather_into(staged.buf[:staged.size], t.buf[:t.size])
+        for q in range(P):
+            be.copy2d(slab, W, staged.ptr + 8 * q * W * slab, slab, full.ptr + 8 * q * slab, slab * P)
         if len(self._full_right) >= 2:
             for k in sorted(self._full_right, key=lambda k: abs(k - idx), reverse=True)[:len(self._full_right) - 1]:
                 del self._full_right[k]

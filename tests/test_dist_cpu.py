@@ -82,7 +82,8 @@ def _worker(rank, world, port, ret):
         eig = mk.Arnoldi(tol=1e-10, krylovdim=10)
         ps, pu = mk.FiniteMPS(As, normalize=True, be=cb), mk.FiniteMPS(As, normalize=True, be=cb)
         es, eu = mdist.ShardedFinEnv(ps, Hg, comm, min_block=2), mk.FinEnv(pu, Hg)
-        ng0, nr0 = comm.n_allgather, comm.n_allreduce
+        ng0, nr0, ns0 = comm.n_allgather, comm.n_allreduce, comm.n_reduce_scatter
+        nt0 = es.n_transfers
         for _ in range(3):
             eps_s = alg.dmrg_sweep(ps, Hg, es, eig, krylov.KrylovWorkspace(cb))
             eps_u = alg.dmrg_sweep(pu, Hg, eu, eig, krylov.KrylovWorkspace(cb))
@@ -94,6 +95,9 @@ def _worker(rank, world, port, ret):
         ok_c = abs(Es - Eu) < 1e-10 * abs(Eu) and all(bool((o == t).all()) for o in outs)
         ok_c = ok_c and abs(max(eps_s) - max(eps_u)) < 1e-8 and es.n_transfers == eu.n_transfers
         ok_c = ok_c and comm.n_allgather > ng0 and comm.n_allreduce > nr0
+        # left-environment updates onto a sharded bond use ONE reduce-scatter each (row input -> row output); an all-reduce
+        # only remains where the output bond is too small to shard; a right-environment gather is ONE collective
+        ok_c = ok_c and comm.n_reduce_scatter > ns0 and (comm.n_reduce_scatter - ns0) + (comm.n_allreduce - nr0) <= es.n_transfers - nt0
         # fixed-budget (benchmark) mode takes the sync-free recurrence with first_image in the blocked layout
         eigf = mk.Arnoldi(fixed_matvecs=4, krylovdim=4)
         alg.dmrg_sweep(ps, Hg, es, eigf, krylov.KrylovWorkspace(cb))
