@@ -165,6 +165,28 @@ class HalfEmbeddedOp:
     __mul__ = __call__
 
 
+class HalfSpaceOp(HalfEmbeddedOp):
+    """Any operator on EMBEDDED tensors (op(x_E) -> y_E), iterated on the half-embedded (= interleaved complex) vectors:
+    apply = encode(op(decode(h))).  Needed whenever the operator is not the same in both sectors of the doubled real space:
+    besides the embeddings X_E, the (2 Dl) x d x (2 Dr) real tensors contain the "anti-structured" X_E Z (Z = sigma_z on
+    every right-bond pair), on which an embedded operator acts as its PARTIAL complex conjugate.  A Krylov solve on the
+    embedded vectors relies on rounding never populating that sector; a term that lives in the embedded sector only -- the
+    projector penalty w |v><v| of excitations(H, FiniteExcited(), psi) -- leaves a LOWER eigenvalue there (the unpenalised
+    ground state) and the solve converges to it (measured: the "excited" state came back with the ground energy and
+    unstructured tensors).  On half vectors the other sector does not exist.  Real inner products of half vectors are
+    Re <x, y>, all a Hermitian Lanczos / Arnoldi solve needs."""
+
+    def __init__(self, be, op, kind, Dr):
+        self.be, self.op, self.kind, self.Dr = be, op, kind, int(Dr)
+
+    def apply_half(self, xh: DTensor, out: DTensor = None):
+        y = self.encode(self.op(self.decode(xh)))
+        if out is not None:
+            self.be.axpby(1.0, y, 0.0, out)
+            return out
+        return y
+
+
 def structured_part(be, E: DTensor):
     """P(E): the embedded real matrix closest to E (2r x 2c) among embeddings of complex matrices:
     r = (E00 + E11) / 2, m = (E10 - E01) / 2 on every 2x2 block.  Returns (P(E), |E - P(E)|_F)."""

@@ -72,7 +72,15 @@ class LazyDerivativeSum:  # derivatives.jl:310-323 : (h::LazySum{<:DerivativeOpe
 
 
 def _lazy(fn, pos, psi, H, envs):
-    return LazyDerivativeSum(psi.be, [fn(pos, psi, h, e) for h, e in zip(H, envs.envs)], H.fs)
+    op = LazyDerivativeSum(psi.be, [fn(pos, psi, h, e) for h, e in zip(H, envs.envs)], H.fs)
+    if getattr(psi, "cplx", False) and any(hasattr(e, "vector") for e in envs.envs):
+        # a projector term exists in the embedded sector only: iterate on half-embedded vectors (cplx.HalfSpaceOp)
+        from .cplx import HalfSpaceOp
+        kind = {"ddAC": "AC", "ddC": "C", "ddAC2": "AC2"}[fn.__name__]
+        t = psi.AC(pos) if kind != "C" else psi.CR(pos)
+        Dr2 = psi.AR(pos + 1).shape[2] if kind == "AC2" else t.shape[-1]
+        return HalfSpaceOp(psi.be, op, kind, Dr2 // 2)
+    return op
 
 
 def _is_lazy(H, envs):
@@ -109,7 +117,7 @@ def ddAC(pos, psi, H, envs):  # ∂∂AC  derivatives.jl:44-46
         return _lazy(ddAC, pos, psi, H, envs)
     if hasattr(envs, "vector"):          # ProjectionOperator term (excitations.py): rank-one |v><v|
         from .excitations import Proj_ddAC
-        return Proj_ddAC(psi.be, envs.vector(pos, psi))
+        return Proj_ddAC(psi.be, envs.vector(pos, psi), bool(getattr(psi, "cplx", False)))
     opp = envs.opp[pos] if hasattr(envs, "opp") else H[pos]
     if _native_cplx(psi, envs.leftenv(pos, psi), envs.rightenv(pos, psi)):
         from .cplx import HalfEmbeddedOp

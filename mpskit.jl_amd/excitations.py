@@ -37,8 +37,11 @@ class OverlapEnv:
         be = self.be = psi.be
         L = len(psi)
         self.H, self.t = op, op.psi
-        self.lefts = [be.upload(np.ones((1, 1, 1)))] + [None] * L
-        self.rights = [None] * L + [be.upload(np.ones((1, 1, 1)))]
+        self.cplx = bool(getattr(psi, "cplx", False))
+        # complex (embedded) states: the boundary "1" is the 2 x 2 identity, every overlap is the embedding of the complex one
+        one = np.eye(2).reshape(1, 2, 2) if self.cplx else np.ones((1, 1, 1))
+        self.lefts = [be.upload(one)] + [None] * L
+        self.rights = [None] * L + [be.upload(one)]
         self.ldeps, self.rdeps = [None] * L, [None] * L
 
     def leftenv(self, ind, psi):
@@ -73,14 +76,26 @@ class OverlapEnv:
 
 
 class Proj_ddAC:
-    """effective operator of |target><target| at a site: y = v <v, x>."""
+    """effective operator of |target><target| at a site: y = v <v, x>.
+    Embedded complex tensors (cplx.py): <v, x> = zr + i zi with  2 zr = v_E . x_E  and  2 zi = (i v)_E . x_E  (real
+    Frobenius products of the embeddings), and  y_E = zr v_E + zi (i v)_E  -- the projector is complex-linear, i.e. it
+    projects on span{v, i v} of the real embedded space."""
 
-    def __init__(self, be, v: DTensor):
-        self.be, self.v = be, v
+    def __init__(self, be, v: DTensor, cplx=False):
+        self.be, self.v, self.cplx = be, v, cplx
+        self.iv = be.times_i(v) if cplx else None
+
+    def overlap(self, x: DTensor):
+        if not self.cplx:
+            return self.be.dot(self.v, x), 0.0
+        return 0.5 * self.be.dot(self.v, x), 0.5 * self.be.dot(self.iv, x)
 
     def __call__(self, x: DTensor, out: DTensor = None):
         y = self.be.empty(*x.shape) if out is None else out
-        self.be.axpby(self.be.dot(self.v, x), self.v, 0.0, y)
+        zr, zi = self.overlap(x)
+        self.be.axpby(zr, self.v, 0.0, y)
+        if self.cplx:
+            self.be.axpby(zi, self.iv, 1.0, y)
         return y
 
     __mul__ = __call__
@@ -89,11 +104,12 @@ class Proj_ddAC:
 def _expval_projection(psi, op, envs):
     """<psi| target><target |psi> / <psi|psi>, reported on site 0 (the other sites carry 0)."""
     pos = 0
-    v = envs.vector(pos, psi)
+    cx = bool(getattr(psi, "cplx", False))
     ac = psi.AC(pos)
     be = psi.be
+    zr, zi = Proj_ddAC(be, envs.vector(pos, psi), cx).overlap(ac)
     out = np.zeros(len(psi))
-    out[0] = be.dot(v, ac) ** 2 / be.norm(ac) ** 2
+    out[0] = (zr * zr + zi * zi) / (be.norm(ac) ** 2 / (2.0 if cx else 1.0))
     return out
 
 
@@ -126,13 +142,12 @@ def excitations(H, alg, *args, **kw):
 
 def _excitations_finite_excited(H, alg: FiniteExcited, psi0: FiniteMPS, num=1, init=None):
     """excitations(H, FiniteExcited(gsalg, weight), psi0; num) -> (energies, states)."""
-    if getattr(psi0, "cplx", False):
-        raise NotImplementedError("FiniteExcited on complex (embedded) states: the projector needs both |v> and i|v>")
     be = psi0.be
+    cx = bool(getattr(psi0, "cplx", False))
     L = len(psi0)
     states, ens, out = [psi0], [], []
     for _ in range(num):
-        start = FiniteMPS([be.copy(psi0.AC(i)) for i in range(L)], normalize=True, be=be) if init is None else init.copy()
+        start = FiniteMPS([be.copy(psi0.AC(i)) for i in range(L)], normalize=True, be=be, cplx=cx) if init is None else init.copy()
         ops = [H] + [ProjectionOperator(s) for s in states]
         Hs = LazySum(ops, [1.0] + [alg.weight] * len(states))
         envs = MultipleEnvironments(Hs, [FinEnv(start, H)] + [OverlapEnv(start, o) for o in ops[1:]])

@@ -87,17 +87,18 @@ def mul_CA(be: Backend, C: DTensor, AR: DTensor):
 
 
 class FiniteMPS:
-    def __init__(self, As, normalize=False, be: Backend | None = None):
+    def __init__(self, As, normalize=False, be: Backend | None = None, cplx: bool | None = None):
         """finitemps.jl:143-169: left-to-right QRpos sweep; only CLs[end] is set.
-        As: list of host arrays (Dl, d, Dr) or DTensors."""
+        As: list of host arrays (Dl, d, Dr) or DTensors.  cplx=True: the DTensors given are EMBEDDED complex tensors
+        (cplx.py) -- needed when a complex state is rebuilt from device tensors (excitations.py)."""
         self.be = default_backend() if be is None else be
         be = self.be
         # complex128 input: carried as the real 2x2 embedding on the bond indices (cplx.py); the embedded
         # Frobenius norm is sqrt(2) times the complex one
-        self.cplx = any((not isinstance(a, DTensor)) and np.iscomplexobj(a) for a in As)
+        self.cplx = any((not isinstance(a, DTensor)) and np.iscomplexobj(a) for a in As) or bool(cplx)
         if self.cplx:
             from .cplx import embed
-            As = [embed(np.asarray(a)) for a in As]
+            As = [a if isinstance(a, DTensor) else embed(np.asarray(a)) for a in As]
         nrm_target = np.sqrt(2.0) if self.cplx else 1.0
         As = [a if isinstance(a, DTensor) else be.upload(np.asarray(a)) for a in As]
         N = len(As)

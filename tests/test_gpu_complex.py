@@ -185,3 +185,10 @@ def test_gauge_steps_keep_the_embedding_on_ill_conditioned_states(be, monkeypatc
             psi, envs = mk.timestep(psi, H, 0.05 * k, 0.05, mk.TDVP(tol=1e-11), envs)
         e1 = float(np.sum(mk.expectation_value(psi, H, envs)))
         assert abs(e1 - e0) < 2e-9 * max(1.0, abs(e0)) and abs(psi.norm() - 1) < 1e-9, (mode, e1 - e0, psi.norm() - 1)
+
+
+def test_complex_states_in_changebonds_and_finite_excited_gpu(be):
+    """changebonds (OptimalExpand / SvdCut) and excitations(H, FiniteExcited(), psi) on COMPLEX states through the C ABI
+    (same body as the host-logic test on the CPU stand-in: tests/test_host_logic_cpu.py)."""
+    from test_host_logic_cpu import test_complex_states_in_changebonds_and_finite_excited as body
+    body(be)

@@ -515,3 +515,58 @@ def test_thick_restart_eigsolve_converges_with_fewer_matvecs(cb):
     assert abs(abs(v @ Q[:, 0]) - 1.0) < 1e-9
     assert np.linalg.norm(M @ v - lam * v) < 5e-12 and res < 1e-12
     assert nmv > 30 and nmv < 0.5 * nmo, (nmv, nmo)          # restarted at least once, and far cheaper
+
+
+def test_complex_states_in_changebonds_and_finite_excited(cb):
+    """SURVEY 8(f).1 / 8(f).4 on COMPLEX states (VERDICT r2 missing #5): changebonds OptimalExpand / SvdCut
+    (optimalexpand.jl:72-102, svdcut.jl:14-23) and excitations(H, FiniteExcited(), psi) (dmrgexcitation.jl:13-36) on the
+    embedded representation (cplx.py) against the oracle's complex arithmetic."""
+    from mpskit_jl_amd import cplx
+    from mpskit_jl_amd.changebonds import changebonds, OptimalExpand, SvdCut
+    rng = np.random.default_rng(29)
+    L, D = 6, 3
+    dims = mo.FiniteMPS.random(L, 2, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.random((1 if i == 0 else dims[i - 1], 2, dims[i])) + 1j * rng.random((1 if i == 0 else dims[i - 1], 2, dims[i]))
+          for i in range(L)]
+    Hg, Ho = mk.heisenberg_XXX(0.5, be=cb), mo.heisenberg_mpo(0.5)
+    pg, po = mk.FiniteMPS(As, normalize=True, be=cb), mo.FiniteMPS(As, normalize=True)
+    v0 = mo.mps_to_vector(po)
+    # OptimalExpand: bond dimensions grow by k, the state is unchanged, every tensor stays an embedding
+    pe, ee = changebonds(pg, Hg, OptimalExpand(trunc_dim=1))
+    qe, _ = mo.changebonds_optimalexpand(po, Ho, truncdim=1)
+    assert pe.cplx and pe.bond_dims() == qe.bond_dims() and max(pe.bond_dims()) > D
+    ve = mo.mps_to_vector(mo.FiniteMPS([pe.download(pe.AL(i)) for i in range(L - 1)] + [pe.download(pe.AC(L - 1))]))
+    assert abs(abs(np.vdot(v0, ve)) - 1.0) < 1e-12
+    for i in range(L):
+        assert cplx.structure_defect(cb.download(pe.AC(i))) < 1e-12
+    # the appended RIGHT directions are the oracle's (dominant right singular subspace of NL^dag H_AC2 AC2 NR^dag; checked
+    # basis-independently below); the completion of leftorth([AC | 0]) is an arbitrary isometry in the reference as well
+    # (whatever QR returns for zero columns), so sweeps from the two expanded states are compared at convergence
+    p1, e1, _ = mk.find_groundstate(pe, Hg, mk.DMRG(tol=1e-11, maxiter=30))
+    q1, f1, _, logq = mo.dmrg(qe, Ho, tol=1e-11, maxiter=30)
+    E1 = float(np.sum(mk.expectation_value(p1, Hg, e1)))
+    Eq = float(np.sum(mo.expectation_value(q1, Ho, f1)).real)
+    E0 = float(np.sum(mk.expectation_value(pg, Hg, mk.FinEnv(pg, Hg))))
+    e_exact = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
+    # (1-site DMRG in the expanded manifold is a local optimisation: the two completions may end in different optima --
+    #  here the oracle's run stalls 8e-4 above the exact energy and the product's reaches it; both must be variational
+    #  and must improve on the unexpanded state)
+    assert e_exact - 1e-9 <= E1 < E0 and e_exact - 1e-9 <= Eq < E0 + 1e-12
+    # SvdCut: truncated state == the oracle's truncated state (up to a phase), Schmidt values kept
+    pc = changebonds(pe, SvdCut(trunc_dim=2))            # (the expanded states are the SAME state on both sides)
+    qc = mo.changebonds_svdcut(qe, truncdim=2)
+    assert pc.bond_dims() == qc.bond_dims() and abs(pc.norm() - 1.0) < 1e-12
+    vc = mo.mps_to_vector(mo.FiniteMPS([pc.download(pc.AL(i)) for i in range(L - 1)] + [pc.download(pc.AC(L - 1))]))
+    assert abs(abs(np.vdot(mo.mps_to_vector(qc), vc)) - 1.0) < 1e-10
+    mid = L // 2 - 1
+    sg = np.linalg.svd(pc.download(pc.CR(mid)), compute_uv=False)
+    assert np.abs(sg - np.linalg.svd(qc.CR(mid), compute_uv=False)).max() < 1e-10
+    # FiniteExcited on a complex ground state: first excited energy == the oracle's (and == dense ED)
+    Lx = 6
+    dx = mo.FiniteMPS.random(Lx, 2, 8, np.random.default_rng(0)).bond_dims()
+    Ax = [rng.random((1 if i == 0 else dx[i - 1], 2, dx[i])) + 1j * rng.random((1 if i == 0 else dx[i - 1], 2, dx[i])) for i in range(Lx)]
+    g0, ge, _ = mk.find_groundstate(mk.FiniteMPS(Ax, normalize=True, be=cb), Hg, mk.DMRG(tol=1e-11, maxiter=20))
+    ens, sts = mk.excitations(Hg, mk.FiniteExcited(gsalg=mk.DMRG(tol=1e-10, maxiter=30), weight=10.0), g0, num=1)
+    w = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, Lx))
+    assert abs(ens[0] - w[1]) < 1e-7 and sts[0].cplx
+    assert abs(float(np.sum(mk.expectation_value(g0, Hg, ge))) - w[0]) < 1e-9
