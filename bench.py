@@ -244,15 +244,17 @@ def main():
         # HBM-side bytes per launch of that kernel from the separate rocprofv3 --pmc passes of tools/pmc_quick.sh
         # (FETCH_SIZE / WRITE_SIZE cannot share a pass with anything else; D = 1024 north-star point).  Attached only
         # if the passes were taken on EXACTLY the kernel sources of this run (hash), else null.
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(pmc) and args.D == 1024 and world == 1:
-            try:
-                pj = json.load(open(pmc))
-                if pj.get("kernel_source_sha256_16") == kernel_source_hash() and top["kernel"] in pj:
-                    roofline["traffic"] = pj[top["kernel"]]
-                    roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/dac_only.py, same kernel sources)"
-            except Exception:
-                pass
+        for tag in ("r03", "r02"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+            if roofline["traffic"] is None and os.path.exists(pmc) and args.D == 1024 and world == 1:
+                try:
+                    pj = json.load(open(pmc))
+                    if pj.get("kernel_source_sha256_16") == kernel_source_hash() and top["kernel"] in pj:
+                        roofline["traffic"] = pj[top["kernel"]]
+                        roofline["traffic_source"] = (f"profiles/{tag}_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                      "passes, tools/dac_only.py, same kernel sources)")
+                except Exception:
+                    pass
 
     # whole-matvec rate at the north-star point (D, d=2, W=5) on the same stream, HIP events
     dac_tflops = None

@@ -93,7 +93,9 @@ def test_torch_rccl_world1_sharded_sweep(be):
         e2 = float(np.sum(mk.expectation_value(ps, H, es)))
         assert abs(e1 - e2) <= 1e-10 * abs(e1), (e1, e2)
         assert np.abs(np.array(e_u) - np.array(e_s)).max() <= 1e-8
-        assert comm.n_allgather > 50 and comm.n_allreduce > 10
+        # (left-environment updates onto a sharded bond: one ncclReduceScatter each; an all-reduce only where the output
+        #  bond is too small to shard)
+        assert comm.n_allgather > 50 and comm.n_reduce_scatter > 10 and comm.n_allreduce >= 1
     finally:
         if created:
             dist.destroy_process_group()
