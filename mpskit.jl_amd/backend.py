@@ -512,6 +512,46 @@ class Backend:
               "mpsk_vorth_step")
         return np.array(out[:]), beta.value
 
+    class _OrthHandle:
+        """result of orth_step_async: .result() waits for the step's scalars only (an event), not for the stream"""
+        __slots__ = ("host", "event", "k")
+
+        def __init__(self, host, event, k):
+            self.host, self.event, self.k = host, event, k
+
+        def result(self):
+            self.event.synchronize()
+            t = self.host.numpy()
+            k = self.k
+            h = t[:k] + t[k:2 * k]
+            return h.copy(), float(np.sqrt(max(t[2 * k], 0.0)))
+
+    def orth_step_async(self, xs, y: DTensor):
+        """orth_step whose scalars travel to the host asynchronously: the call returns once the CGS2 / normalisation
+        kernels and the device-to-host copy of the 2k+1 scalars are enqueued.  A tolerance-mode Krylov loop enqueues the
+        NEXT matvec before it reads the handle, so the GPU works while the host takes its per-step decision (the stream used
+        to drain at every step: 36 % idle in the VUMPS run of BASELINE config 3, profiles/r03_small_D_kernel_stats.log)."""
+        torch = _torch()
+        k = len(xs)
+        n = 2 * k + 1
+        ring = getattr(self, "_orth_ring", None)
+        if ring is None:
+            ring = self._orth_ring = {"dev": torch.empty(4 * 544, dtype=torch.float64, device=self.device),
+                                      "host": [torch.empty(544, dtype=torch.float64).pin_memory() for _ in range(4)],
+                                      "i": 0}
+        if n > 544:
+            raise MpskError("orth_step_async: more than 271 basis vectors")
+        i = ring["i"]
+        ring["i"] = (i + 1) % 4
+        dev = ring["dev"][i * 544:i * 544 + n]
+        check(self.lib.mpsk_vorth_step_dev(self.ctx, y.size, k, self._ptrs(xs), y.ptr, dev.data_ptr()), "mpsk_vorth_step_dev")
+        with torch.cuda.stream(self.torch_stream):
+            host = ring["host"][i][:n]
+            host.copy_(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.torch_stream)
+        return Backend._OrthHandle(host, ev, k)
+
     def orth_step_dev(self, xs, y: DTensor, slot: DTensor, offset: int):
         """orth_step without the host sync: the 2k+1 scalars go to slot[offset : offset + 2k + 1] on the device."""
         check(self.lib.mpsk_vorth_step_dev(self.ctx, y.size, len(xs), self._ptrs(xs), y.ptr, slot.ptr + 8 * offset),

@@ -116,27 +116,54 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
     Hm = np.zeros((m + 1, m))
     k, conv = 0, False
     sv = None
+    # One-step-ahead expansion (device backends with orth_step_async): step k + 1 (matvec, Gram-Schmidt, normalisation -- none
+    # of which needs the host) is enqueued BEFORE the host reads the scalars of step k and takes the eager convergence
+    # decision, so the stream does not drain once per Krylov step.  If step k turns out to be the last one, the speculative
+    # step is discarded: it only wrote basis[k + 2], which the Ritz vector of step k does not involve (at most one wasted
+    # matvec per solve, counted in nmv).
+    spec = hasattr(be, "orth_step_async") and fixed_matvecs is None
+
+    def account(kk, h, beta):
+        """column kk of the projected matrix is known: eager convergence test of the (kk + 1)-dimensional space"""
+        nonlocal lam, sv, res, S, ev
+        Hm[:kk + 1, kk] = h
+        Hm[kk + 1, kk] = beta
+        Hk = Hm[:kk + 1, :kk + 1]
+        ev, S = np.linalg.eigh((Hk + Hk.T) / 2)
+        lam, sv = ev[0], S[:, 0]
+        res = abs(Hm[kk + 1, :kk + 1] @ sv)               # |(last row of the (k+1) x k matrix) . s| = Ritz residual norm
+        done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
+        # breakdown: the Krylov space is invariant (always the case once k reaches the vector-space dimension)
+        breakdown = beta <= 1e-13 * max(np.abs(Hk).max(), 1e-300) or kk + 1 >= x0.size
+        return (fixed_matvecs is None and res < tol) or breakdown or done_fixed
+
+    S = ev = None
     for _restart in range(maxiter):
+        pending = None                                    # (column index, handle) whose scalars are still in flight
         while k < m:
             w = basis[k + 1]
             matvec(basis[k], w)
             if nmv == 0 and first_image is not None:
                 be.axpby(1.0, w, 0.0, first_image)
             nmv += 1
+            if spec:
+                hnd = be.orth_step_async(basis[:k + 1], w)
+                if pending is not None and account(pending[0], *pending[1].result()):
+                    k, conv = pending[0] + 1, True        # converged one step earlier: drop the speculative step
+                    pending = None
+                    break
+                pending = (k, hnd)
+                k += 1
+                continue
             h, beta = be.orth_step(basis[:k + 1], w)      # CGS2 + normalise, one host sync
-            Hm[:k + 1, k] = h
-            Hm[k + 1, k] = beta
             k += 1
-            Hk = Hm[:k, :k]
-            ev, S = np.linalg.eigh((Hk + Hk.T) / 2)
-            lam, sv = ev[0], S[:, 0]
-            res = abs(Hm[k, :k] @ sv)                     # |(last row of the (k+1) x k matrix) . s| = Ritz residual norm
-            done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
-            # breakdown: the Krylov space is invariant (always the case once k reaches the vector-space dimension)
-            breakdown = beta <= 1e-13 * max(np.abs(Hk).max(), 1e-300) or k >= x0.size
-            if (fixed_matvecs is None and res < tol) or breakdown or done_fixed:
+            if account(k - 1, h, beta):
                 conv = True
                 break
+        if pending is not None:
+            kk = pending[0]
+            if account(kk, *pending[1].result()):
+                k, conv = kk + 1, True
         if conv or _restart == maxiter - 1:
             break
         # shrink: keep the lowest Ritz vectors (KrylovKit: keep = div(3 krylovdim + 2 converged, 5), converged = 0 here)
@@ -325,19 +352,37 @@ def gmres(be: Backend, matvec, b: DTensor, x0: DTensor, tol=1e-12, krylovdim=30,
         be.axpby(1.0 / beta, r, 0.0, V[0])
         Hm = np.zeros((krylovdim + 1, krylovdim))
         k, y = 0, None
+        spec = hasattr(be, "orth_step_async")      # one-step-ahead expansion, as in eigsolve_sr
+
+        def account(kk, h, hn):
+            nonlocal y, res
+            Hm[:kk + 1, kk] = h
+            Hm[kk + 1, kk] = hn
+            e1 = np.zeros(kk + 2)
+            e1[0] = beta
+            y, *_ = np.linalg.lstsq(Hm[:kk + 2, :kk + 1], e1, rcond=None)
+            res = np.linalg.norm(Hm[:kk + 2, :kk + 1] @ y - e1)
+            return res <= tol or hn < 1e-300
+
+        pending, done = None, False
         while k < krylovdim:
             w = V[k + 1]
             matvec(V[k], w)
+            if spec:
+                hnd = be.orth_step_async(V[:k + 1], w)
+                if pending is not None and account(pending[0], *pending[1].result()):
+                    k, done, pending = pending[0] + 1, True, None
+                    break
+                pending = (k, hnd)
+                k += 1
+                continue
             h, hn = be.orth_step(V[:k + 1], w)
-            Hm[:k + 1, k] = h
-            Hm[k + 1, k] = hn
             k += 1
-            e1 = np.zeros(k + 1)
-            e1[0] = beta
-            y, *_ = np.linalg.lstsq(Hm[:k + 1, :k], e1, rcond=None)
-            res = np.linalg.norm(Hm[:k + 1, :k] @ y - e1)
-            if res <= tol or hn < 1e-300:
+            if account(k - 1, h, hn):
                 break
+        if pending is not None and not done:
+            if account(pending[0], *pending[1].result()):
+                k = pending[0] + 1
         be.lincomb(V[:k], y, out=tmp)
         be.axpby(1.0, tmp, 1.0, x)
         if res <= tol:
