@@ -513,44 +513,52 @@ class Backend:
         return np.array(out[:]), beta.value
 
     class _OrthHandle:
-        """result of orth_step_async: .result() waits for the step's scalars only (an event), not for the stream"""
-        __slots__ = ("host", "event", "k")
+        """result of orth_step_async: .result() waits for the step's scalars only (an event), not for the stream, and
+        hands the (device, pinned host) buffer pair back to the backend's free list"""
+        __slots__ = ("be", "slot", "event", "k")
 
-        def __init__(self, host, event, k):
-            self.host, self.event, self.k = host, event, k
+        def __init__(self, be, slot, event, k):
+            self.be, self.slot, self.event, self.k = be, slot, event, k
 
         def result(self):
             self.event.synchronize()
-            t = self.host.numpy()
             k = self.k
-            h = t[:k] + t[k:2 * k]
-            return h.copy(), float(np.sqrt(max(t[2 * k], 0.0)))
+            t = self.slot[1].numpy()
+            h = (t[:k] + t[k:2 * k]).copy()
+            beta = float(np.sqrt(max(t[2 * k], 0.0)))
+            self.be._orth_free.append(self.slot)
+            self.slot = None
+            return h, beta
+
+        def __del__(self):                      # a speculative step that was dropped: the buffers go back as well
+            if self.slot is not None:           # (stream order: the dropped copy completes before any later use of them)
+                self.be._orth_free.append(self.slot)
+
+    ORTH_SLOT = 544                             # 2 * 271 + 2 doubles
 
     def orth_step_async(self, xs, y: DTensor):
         """orth_step whose scalars travel to the host asynchronously: the call returns once the CGS2 / normalisation
         kernels and the device-to-host copy of the 2k+1 scalars are enqueued.  A tolerance-mode Krylov loop enqueues the
         NEXT matvec before it reads the handle, so the GPU works while the host takes its per-step decision (the stream used
-        to drain at every step: 36 % idle in the VUMPS run of BASELINE config 3, profiles/r03_small_D_kernel_stats.log)."""
+        to drain at every step: 36 % idle in the VUMPS run of BASELINE config 3, profiles/r03_small_D_kernel_stats.log).
+        Every handle owns its buffers until it is read or dropped: solvers nest (the quasiparticle effective Hamiltonian
+        runs GMRES solves inside the matvec of an outer eigensolver that has a handle in flight)."""
         torch = _torch()
         k = len(xs)
         n = 2 * k + 1
-        ring = getattr(self, "_orth_ring", None)
-        if ring is None:
-            ring = self._orth_ring = {"dev": torch.empty(4 * 544, dtype=torch.float64, device=self.device),
-                                      "host": [torch.empty(544, dtype=torch.float64).pin_memory() for _ in range(4)],
-                                      "i": 0}
-        if n > 544:
+        if n > self.ORTH_SLOT:
             raise MpskError("orth_step_async: more than 271 basis vectors")
-        i = ring["i"]
-        ring["i"] = (i + 1) % 4
-        dev = ring["dev"][i * 544:i * 544 + n]
-        check(self.lib.mpsk_vorth_step_dev(self.ctx, y.size, k, self._ptrs(xs), y.ptr, dev.data_ptr()), "mpsk_vorth_step_dev")
+        free = getattr(self, "_orth_free", None)
+        if free is None:
+            free = self._orth_free = []
+        slot = free.pop() if free else (torch.empty(self.ORTH_SLOT, dtype=torch.float64, device=self.device),
+                                        torch.empty(self.ORTH_SLOT, dtype=torch.float64).pin_memory())
+        check(self.lib.mpsk_vorth_step_dev(self.ctx, y.size, k, self._ptrs(xs), y.ptr, slot[0].data_ptr()), "mpsk_vorth_step_dev")
         with torch.cuda.stream(self.torch_stream):
-            host = ring["host"][i][:n]
-            host.copy_(dev, non_blocking=True)
+            slot[1][:n].copy_(slot[0][:n], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.torch_stream)
-        return Backend._OrthHandle(host, ev, k)
+        return Backend._OrthHandle(self, slot, ev, k)
 
     def orth_step_dev(self, xs, y: DTensor, slot: DTensor, offset: int):
         """orth_step without the host sync: the 2k+1 scalars go to slot[offset : offset + 2k + 1] on the device."""
