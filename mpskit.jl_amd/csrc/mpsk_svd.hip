@@ -396,19 +396,21 @@ __device__ __forceinline__ void eig2_r_step(double (*Ms)[J2 + 1], double* __rest
   for (int off = 1; off < 8; off <<= 1) {
     al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
   }
-  // rotation parameters: see jacobi_eig_kernel (fp32 tangent, fp64-polished cosine)
+  // Rotation parameters in ~20 fp64 operations (the first kernel's fp32 detour with frexp / ldexp / conversions is ~45):
+  // the ANGLE only needs to be approximately right, so zeta, sqrt(1 + zeta^2) and t come from the hardware reciprocal /
+  // rsqrt approximations (v_rcp_f64 / v_rsq_f64, ~1e-8 relative); (c, s) must be orthonormal to fp64 accuracy, so
+  // c = (1 + t^2)^(-1/2) is polished by two Newton steps and s = c t.  No overflow: a rotation is only formed when
+  // gamma^2 > 1e-34 alpha beta, i.e. |zeta| < ~1e17 |beta - alpha| / sqrt(alpha beta) stays far inside the fp64 range.
   double c = 1.0, sn = 0.0;
   const double ab = al * be, gg = ga * ga;
   if (gg > 1.0e-34 * ab) {
-    const double num = (be - al) * 0.5;
-    int ex;
-    (void)frexp(fmax(fabs(num), fabs(ga)), &ex);
-    const float zf = (float)ldexp(num, -ex) * __frcp_rn((float)ldexp(ga, -ex));
-    const float az = fabsf(zf);
-    const float tf = copysignf(1.0f, zf) * (az > 1.0e4f ? 0.5f * __frcp_rn(az) : __frcp_rn(az + __fsqrt_rn(1.0f + zf * zf)));
-    const double t = (double)tf;
-    const double x = 1.0 + t * t;
-    double r = (double)__frsqrt_rn((float)x);
+    const double zeta = 0.5 * (be - al) * __builtin_amdgcn_rcp(ga);
+    const double az = fabs(zeta);
+    const double w = fma(zeta, zeta, 1.0);
+    const double den = az + w * __builtin_amdgcn_rsq(w);          // |zeta| + sqrt(1 + zeta^2)
+    const double t = copysign(__builtin_amdgcn_rcp(den), zeta);
+    const double x = fma(t, t, 1.0);
+    double r = __builtin_amdgcn_rsq(x);
     r = r * (1.5 - 0.5 * x * r * r);
     r = r * (1.5 - 0.5 * x * r * r);
     c = r;
