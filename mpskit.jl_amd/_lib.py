@@ -147,6 +147,7 @@ COMM_SIGNATURES = {
     "mpsk_comm_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mpsk_comm_allgather": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "mpsk_comm_allreduce_sum": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "mpsk_comm_reduce_scatter_sum": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "mpsk_comm_hac_apply": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int],
 }
 COMM_ID_BYTES = 128

@@ -87,6 +87,14 @@ int mpsk_comm_allreduce_sum(mpsk_comm* c, void* buf, size_t count) {
   return MPSK_OK;
 }
 
+int mpsk_comm_reduce_scatter_sum(mpsk_comm* c, const void* send, void* recv, size_t count) {
+  if (!c || !send || !recv) return cfail("mpsk_comm_reduce_scatter_sum: NULL argument");
+  hipStream_t s;
+  if (int rc = stream_of(c, &s)) return rc;
+  NCCLCHK(ncclReduceScatter(send, recv, count, ncclDouble, ncclSum, c->nc, s));
+  return MPSK_OK;
+}
+
 int mpsk_comm_hac_apply(mpsk_comm* c, mpsk_hac* h, const void* xblk, void* yblk, int Dl, int d, int Dr) {
   if (!c || !h || !xblk || !yblk) return cfail("mpsk_comm_hac_apply: NULL argument");
   if (Dl <= 0 || d <= 0 || Dr <= 0 || Dl % c->world != 0) return cfail("mpsk_comm_hac_apply: world must divide Dl");

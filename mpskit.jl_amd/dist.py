@@ -188,6 +188,14 @@ class LibComm(Comm):
         _lib.check_comm(self.lib.mpsk_comm_allreduce_sum(self.handle, buf.data_ptr(), buf.numel()), "mpsk_comm_allreduce_sum")
         return buf
 
+    def reduce_scatter_sum(self, out, inp):
+        from . import _lib
+        self.n_reduce_scatter += 1
+        self.bytes_reduce_scatter += inp.numel() * 8
+        _lib.check_comm(self.lib.mpsk_comm_reduce_scatter_sum(self.handle, inp.data_ptr(), out.data_ptr(), out.numel()),
+                        "mpsk_comm_reduce_scatter_sum")
+        return out
+
     def hac_apply(self, hac, xb, out):
         """mpsk_comm_hac_apply: local rows into this rank's block of `out` + the in-place all-gather, one C call."""
         from . import _lib

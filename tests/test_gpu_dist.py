@@ -37,8 +37,10 @@ def test_libmpsk_comm_world1(be):
         ref = t.clone()
         comm.all_gather_into(t, t)                  # in place
         comm.all_reduce_sum(t)
+        rs = torch.empty_like(t)
+        comm.reduce_scatter_sum(rs, t)              # world 1: the single chunk comes back unchanged
         be.synchronize()
-        assert torch.equal(t, ref)
+        assert torch.equal(t, ref) and torch.equal(rs, ref)
         rng = np.random.default_rng(4)
         D, d, W = 128, 2, 5
         H = mk.heisenberg_XXX(0.5, be=be)
@@ -57,7 +59,7 @@ def test_libmpsk_comm_world1(be):
         alg.dmrg_sweep(ps, H, es, eig, krylov.KrylovWorkspace(be))
         e1 = float(np.sum(mk.expectation_value(psi, H, eu)))
         e2 = float(np.sum(mk.expectation_value(ps, H, es)))
-        assert abs(e1 - e2) <= 1e-10 * abs(e1) and comm.n_allgather > 10
+        assert abs(e1 - e2) <= 1e-10 * abs(e1) and comm.n_allgather > 10 and comm.n_reduce_scatter > 3
     finally:
         comm.close()
 
