@@ -327,6 +327,17 @@ __global__ __launch_bounds__(256) void jacobi_eig_kernel(const double* __restric
 //     rotations of step t while the other four work on step t + 1 (one barrier per step, (c, s) double-buffered).
 // LDS traffic per step halves and W's rotations leave the critical path.
 constexpr int EIG2_THREADS = 320;
+#ifndef MPSK_EIG2_DIAG
+#define MPSK_EIG2_DIAG 0      // timing diagnostics only (wrong results): 1 = wave 4 idles, 2 = waves 0-3 idle
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ double sv_dpp(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 
 __host__ __device__ constexpr int eig2_lo(int t, int pk) {
   const int a = (pk == 0) ? J2 - 1 : (t + pk) % (J2 - 1), b = (pk == 0) ? t : (t + (J2 - 1) - pk) % (J2 - 1);
@@ -392,10 +403,11 @@ __device__ __forceinline__ void eig2_r_step(double (*Ms)[J2 + 1], double* __rest
   double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { al += rp[i] * rp[i]; be += rq[i] * rq[i]; ga += rp[i] * rq[i]; }
-#pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
-    al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
-  }
+  // 8-lane sums by DPP (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror): VALU moves with a few cycles of
+  // latency; __shfl_xor compiles to ds_bpermute_b32, an LDS-crossbar round trip per stage on the serial path of the step
+  al += sv_dpp<0xB1>(al); be += sv_dpp<0xB1>(be); ga += sv_dpp<0xB1>(ga);
+  al += sv_dpp<0x4E>(al); be += sv_dpp<0x4E>(be); ga += sv_dpp<0x4E>(ga);
+  al += sv_dpp<0x141>(al); be += sv_dpp<0x141>(be); ga += sv_dpp<0x141>(ga);
   // Rotation parameters in ~20 fp64 operations (the first kernel's fp32 detour with frexp / ldexp / conversions is ~45):
   // the ANGLE only needs to be approximately right, so zeta, sqrt(1 + zeta^2) and t come from the hardware reciprocal /
   // rsqrt approximations (v_rcp_f64 / v_rsq_f64, ~1e-8 relative); (c, s) must be orthonormal to fp64 accuracy, so
@@ -432,7 +444,7 @@ __device__ __forceinline__ void eig2_r_step(double (*Ms)[J2 + 1], double* __rest
 template <int ST>
 __device__ __forceinline__ void eig2_w_phases(double (*cs)[2 * 32], double (&w)[J2]) {
   if constexpr (ST < J2) {
-    if constexpr (ST >= 1) eig2_w_apply<ST - 1>(w, cs[(ST - 1) & 1]);
+    if constexpr (ST >= 1 && MPSK_EIG2_DIAG != 1) eig2_w_apply<ST - 1>(w, cs[(ST - 1) & 1]);
     __syncthreads();
     eig2_w_phases<ST + 1>(cs, w);
   }
@@ -475,6 +487,8 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
   }
   __syncthreads();
   EIG2_STAMP(1);
+  // symmetrise and measure in ONE pass: the thread that owns (i, j), i < j, also owns (j, i); max |cos|^2 through the
+  // hardware reciprocal (the convergence decision has 1e-8 of slack), one square root per workgroup at the end
   double mx = 0.0;
   if (rw) {
     for (int e = tid; e < J2 * J2; e += 256) {
@@ -482,34 +496,23 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
       if (i < j) {
         const double a = 0.5 * (Ms[i][j] + Ms[j][i]);
         const double dd = Ms[i][i] * Ms[j][j];
-        const double r = (a == 0.0) ? 0.0 : (dd > 0.0 ? fabs(a) / sqrt(dd) : 1.0);
-        mx = fmax(mx, r);
+        const double r2 = (a == 0.0) ? 0.0 : (dd > 0.0 ? a * a * __builtin_amdgcn_rcp(dd) : 1.0);
+        mx = fmax(mx, r2);
+        Ms[i][j] = a;
+        Ms[j][i] = a;
       }
     }
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
     if (lane == 0) red[wave] = mx;
   }
   __syncthreads();
-  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  mx = sqrt(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
   if (tid == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(mx));
   double* Wp = Wout + (size_t)p * J2 * J2;
   if (mx <= tol) {                           // (uniform over the workgroup)
     for (int e = tid; e < J2 * J2; e += EIG2_THREADS) Wp[e] = (e % J2 == e / J2) ? 1.0 : 0.0;
     return;
   }
-  __syncthreads();
-  if (rw)
-    for (int e = tid; e < J2 * J2; e += 256) {
-      const int i = e % J2, j = e / J2;
-      if (i < j) { const double a = 0.5 * (Ms[i][j] + Ms[j][i]); Ms[i][j] = a; }
-    }
-  __syncthreads();
-  if (rw)
-    for (int e = tid; e < J2 * J2; e += 256) {
-      const int i = e % J2, j = e / J2;
-      if (i > j) Ms[i][j] = Ms[j][i];
-    }
-  __syncthreads();
   EIG2_STAMP(2);
   // ---- (1) Cholesky of the unit-diagonal scaled Gram matrix, rows four at a time (see jacobi_eig_kernel)
   const int wr = (wave >> 1) & 1, wc = wave & 1, lr = lane >> 4, lc = lane & 15;
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
       __syncthreads();
       int rotated = 0;
       for (int st = 0; st < J2; ++st) {      // phase st: step st (< 63); wave 4 applies step st - 1 meanwhile
-        if (st < J2 - 1) eig2_r_step(Ms, cs[st & 1], st, pk, pj, &rotated);
+        if (st < J2 - 1 && MPSK_EIG2_DIAG != 2) eig2_r_step(Ms, cs[st & 1], st, pk, pj, &rotated);
         __syncthreads();
       }
       if (rotated) any_rot = 1;
