@@ -81,10 +81,17 @@ int mpsk_ctx_qr_stats(mpsk_ctx* ctx, long* n_chol, long* n_house, long* n_fallba
  * repeated with the shift of Fukaya et al. (s = 11 (mn + n(n+1)) u ||A||_F^2); counted in n_chol when the repeat succeeds */
 int mpsk_ctx_qr_retries(mpsk_ctx* ctx, long* n_retry);
 /* tsvd algorithm switch: 0 = Jacobi on theta directly; 1 = the tall orientation of theta is factored with QRpos first and
- * the block-Jacobi iteration runs on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra); 2 (default)
+ * the block-Jacobi iteration runs on R^T (Drmac-Veselic preconditioning; far fewer sweeps on graded spectra); 2
  * = additionally R^T = Q1 R1 and the iteration runs on R1^T (V-free in mpsk_tsplit, with accumulated rotations in
  * mpsk_tsvd: 15 -> 10 sweeps on graded 4096^2 tensors for one more n x n QRpos).  mpsk_ctx_svd_stats returns the number of
  * Jacobi sweeps of the last mpsk_tsvd / mpsk_tsplit.
+ * 3 (default) = mode 2, and mpsk_tsplit becomes TRUNCATION-AWARE when max_keep > 0 and r = max_keep + max(64, max_keep / 2) (rounded
+ * up to 64) is at most 5/8 of min(m, n): a randomized subspace iteration on the GEMM core finds the dominant r-dimensional
+ * subspace, the Jacobi split runs on r columns instead of min(m, n), and the result is accepted only after a CHECK -- the
+ * part of the kept triplets outside the iterated subspace, || U_k^T theta (I - W W^T) ||_F <= 1e-12 ||theta||_F
+ * (MPSK_SPLIT_TOL) -- otherwise the iteration continues or the call falls through to mode 2 (flat spectra).  Same AL / C / AR
+ * contract; S then holds the r leading values and NaN behind them.  mpsk_ctx_split_stats: path of the last mpsk_tsplit
+ * (0 full iteration, 1 subspace stage accepted, 2 stage gave up -> full iteration), subspace iterations, check value.
  * Mode 0 has no relative accuracy on matrices whose COLUMNS are nearly parallel (condition number of the column-scaled
  * matrix >= 1/u, e.g. U diag(logspace(0,-14)) V^T behind random orthogonal factors): every rotation against an O(1) column
  * injects rounding noise u |a_big| into columns whose norm is of that order, so their mutual cosines stay O(1) and the
@@ -93,6 +100,7 @@ int mpsk_ctx_qr_retries(mpsk_ctx* ctx, long* n_retry);
  * what the QR preconditioning of modes 1 / 2 produces.) */
 int mpsk_ctx_set_svd_mode(mpsk_ctx* ctx, int precondition);
 int mpsk_ctx_svd_stats(mpsk_ctx* ctx, int* last_sweeps);
+int mpsk_ctx_split_stats(mpsk_ctx* ctx, int* path, int* iterations, double* residual);   /* any pointer may be NULL */
 /* tile override for benchmarking the GEMM core (0,0 restores the heuristic) */
 int mpsk_ctx_force_tile(mpsk_ctx* ctx, int bm, int bn);
 
@@ -225,7 +233,7 @@ int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, 
  * accumulating the Jacobi rotations (a third less memory traffic per round): AL, AR are isometries to rounding,
  * AL C AR = theta projected on the kept singular subspace, C is TRIANGULAR instead of diag(S) -- lower or upper depending on
  * the orientation and on the svd mode (mode 2 delivers the left vectors of the tall orientation, the other factor comes from
- * an LQpos); S (min(m, n) doubles) receives all singular values, *kept = k.
+ * an LQpos); S (min(m, n) doubles) receives all singular values (svd mode 3: see mpsk_ctx_set_svd_mode), *kept = k.
  * Buffers: AL m x min(m,n), C min(m,n)^2, AR min(m,n) x n (only the leading k columns / rows are written). */
 int mpsk_tsplit(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
                 void* AL, int ldal, void* C, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mpsk_ctx_qr_stats": [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "mpsk_ctx_set_svd_mode": [C.c_void_p, C.c_int],
     "mpsk_ctx_svd_stats": [C.c_void_p, C.POINTER(C.c_int)],
+    "mpsk_ctx_split_stats": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)],
     "mpsk_prof_enable": [C.c_void_p, C.c_int],
     "mpsk_prof_summary": [C.c_void_p, C.c_char_p, C.c_size_t],
     "mpsk_malloc": [C.c_void_p, C.c_size_t, c_void_pp],

@@ -92,13 +92,20 @@ class Backend:
         return {"cholqr3": a.value, "householder": b.value, "fallback": f.value, "robust": r.value}
 
     def set_svd_mode(self, precondition=True):
-        """0 / False: Jacobi on theta itself; 1 / True: QR-preconditioned; 2: QR + QR of R^T (mpsk_tsplit only)."""
+        """0 / False: Jacobi on theta itself; 1 / True: QR-preconditioned; 2: QR + QR of R^T; 3: 2 + truncation-aware
+        mpsk_tsplit (subspace iteration, checked; include/mpsk.h)."""
         check(self.lib.mpsk_ctx_set_svd_mode(self.ctx, int(precondition)), "mpsk_ctx_set_svd_mode")
 
     def svd_sweeps(self):
         n = C.c_int()
         check(self.lib.mpsk_ctx_svd_stats(self.ctx, C.byref(n)), "mpsk_ctx_svd_stats")
         return n.value
+
+    def split_stats(self):
+        """last mpsk_tsplit: {"path": 0 full iteration / 1 subspace stage accepted / 2 stage gave up, "iterations", "residual"}"""
+        p, it, r = C.c_int(), C.c_int(), C.c_double()
+        check(self.lib.mpsk_ctx_split_stats(self.ctx, C.byref(p), C.byref(it), C.byref(r)), "mpsk_ctx_split_stats")
+        return {"path": p.value, "iterations": it.value, "residual": r.value}
 
     def prof_enable(self, on=True):
         check(self.lib.mpsk_prof_enable(self.ctx, int(on)), "mpsk_prof_enable")

@@ -64,7 +64,11 @@ struct mpsk_ctx {
   bool coef_pending = false;
   int dtype = MPSK_F64;         // scalar type of the slice-less entry points (mpsk_ctx_set_dtype)
   int last_svd_sweeps = 0;
-  int svd_precondition = 2;     // mpsk_ctx_set_svd_mode: 0 plain, 1 QR-preconditioned, 2 QR + QR of R^T (mpsk_tsplit V-free, mpsk_tsvd with accumulated rotations)
+  int split_skip = 0, split_backoff = 0;           // calls that skip the stage after it gave up
+  int split_q_hint = 8;         // subspace iterations the next truncation-aware mpsk_tsplit starts with (what the last one needed)
+  int last_split_iters = 0, last_split_path = 0;   // path: 0 full iteration (mode <= 2 / not applicable), 1 subspace stage, 2 stage gave up -> full
+  double last_split_resid = 0.0;
+  int svd_precondition = 3;     // mpsk_ctx_set_svd_mode: 0 plain, 1 QR-preconditioned, 2 QR + QR of R^T (mpsk_tsplit V-free, mpsk_tsvd with accumulated rotations), 3 = 2 + truncation-aware mpsk_tsplit
   int qr_mode = 0;              // 0 auto (CholeskyQR3 + Householder fallback), 1 Householder, 2 CholeskyQR3 only
   int* d_flag = nullptr;
   long n_qr_chol = 0, n_qr_house = 0, n_qr_fallback = 0, n_qr_robust = 0, n_qr_retry = 0;
@@ -1348,7 +1352,7 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
   if (c->svd_precondition && nn > 64) {
     // QR-preconditioned one-sided Jacobi: A' = theta or theta^T (tall) = Qb Rb, Jacobi on Rb^T
     const auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };   // keep every sub-buffer 16-byte aligned
-    const bool dbl = c->svd_precondition == 2;
+    const bool dbl = c->svd_precondition >= 2;
     const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);
     const size_t x_d = dbl ? 3 * r_d : 0;                              // Q1 / R^T, U'', Vh'' of the double preconditioning
     const size_t qws = sizeof(double) * qr_ws_doubles(mm, nn), sws = tsvd_workspace_bytes(nn, nn);
@@ -1408,6 +1412,53 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
 // R^T -> singular values and the singular vectors of ONE side (exact, orthonormal); the other factor is rebuilt from
 // theta itself and re-orthonormalised by QRpos / LQpos, so AL, AR are isometries to rounding and
 // AL C AR = theta projected on the kept singular subspace; C is triangular instead of diag(S) (S is returned too).
+// ---- truncation-aware stage of mpsk_tsplit (svd mode 3) ---------------------------------------------------------------
+// When only k = max_keep << n singular triplets are kept, the block-Jacobi iteration on all n columns (127 rounds a sweep at
+// n = 4096, ~10 sweeps) is replaced by
+//   1. a randomized subspace iteration for the dominant right subspace of the tall orientation A' (mm x nn):
+//        Y <- orth(A'^T orth(A' Y)),   Y: nn x r,  r = k + max(64, k / 2) rounded up to 64
+//      -- two GEMMs on the MFMA core and two ONE-pass shifted CholeskyQR re-conditionings per iteration (only the span
+//      matters; the error of the i-th direction shrinks by (sigma_{r+1} / sigma_i)^2 per iteration);
+//   2. W = QRpos(Y) (working accuracy), B' = A' W (mm x r), and the usual preconditioned V-free Jacobi split on B': r
+//      columns instead of nn (r = 1536 of 4096: 47 rounds a sweep instead of 127, 24 pairs a round instead of 64);
+//   3. a CHECK, not an estimate: with U_k the kept left vectors and M = U_k^T A' (formed anyway for the LQpos / QRpos that
+//      delivers the other factor),  rho = || M (I - W W^T) ||_F / ||theta||_F  is the part of the kept triplets that lies
+//      outside the iterated subspace.  rho <= MPSK_SPLIT_TOL (1e-12): done.  Otherwise the iteration continues from the r
+//      left Ritz vectors for the number of iterations the measured Ritz ratio predicts, or -- if that would cost more than
+//      the full iteration -- the call falls through to mode 2.  Nothing is returned that has not passed the check.
+// M is computed with the full theta, so C . AR = U_k^T theta exactly as in mode 2; S holds the r leading values (Ritz values
+// of a converged subspace: errors O(rho^2)), the remaining entries are NaN.
+__global__ __launch_bounds__(256) void split_fill_kernel(double* __restrict__ y, int64_t n, unsigned seed) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)(e & 0xffffffffu) * 0x9E3779B1u ^ ((unsigned)(e >> 32) + seed) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    y[e] = ((double)h + 0.5) * (2.0 / 4294967296.0) - 1.0;       // uniform in (-1, 1)
+  }
+}
+__global__ __launch_bounds__(256) void split_fill_nan_kernel(double* __restrict__ y, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) y[e] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+struct SplitSub {             // state of the subspace stage across refinements
+  int r = 0;
+  double *Yb = nullptr, *Zb = nullptr, *Wb = nullptr, *Bp = nullptr;   // nn x r, mm x r, nn x r, mm x r
+};
+
+// q iterations  Y <- orth1(A'^T orth1(A' Y))  starting from Yb (nn x r); result in Yb.  Zb / Wb / Bp are scratch.
+static int split_iterate(mpsk_ctx* c, int mm, int nn, const double* Ap, int lda, const SplitSub& sb, int q) {
+  const int r = sb.r;
+  for (int i = 0; i < q; ++i) {
+    GemmArgs g = mk(Ap, sb.Yb, sb.Zb, mm, r, nn, lda, nn, mm);
+    HIPCHK(gemm_f64(g, c->stream));
+    HIPCHK(cholqr1_orth(mm, r, sb.Zb, mm, sb.Bp, mm, (double*)c->ws, c->d_flag, c->stream));
+    GemmArgs g2 = mk(Ap, sb.Bp, sb.Wb, nn, r, mm, lda, mm, nn, 1, 0);
+    HIPCHK(gemm_f64(g2, c->stream));
+    HIPCHK(cholqr1_orth(nn, r, sb.Wb, nn, sb.Yb, nn, (double*)c->ws, c->d_flag, c->stream));
+  }
+  return MPSK_OK;
+}
+
 int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
                 void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
   REQUIRE(c && theta && AL && Cm && AR && S && kept && disc_norm, "NULL argument");
@@ -1420,9 +1471,21 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   c->defer_next = false;                       // (the inner mpsk_qrpos / mpsk_lqpos calls complete at once)
   HIPCHK(hipSetDevice(c->device));
   const auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  // truncation-aware stage: worth it while r columns are well below nn (the Jacobi part scales ~ r^2, the iteration ~ q r)
+  static const double sub_over = getenv("MPSK_SPLIT_OVERSAMPLE") ? atof(getenv("MPSK_SPLIT_OVERSAMPLE")) : 0.5;
+  static const double sub_tol = getenv("MPSK_SPLIT_TOL") ? atof(getenv("MPSK_SPLIT_TOL")) : 1.0e-12;
+  int r_sub = 0;
+  if (c->split_skip > 0) --c->split_skip;          // (backing off after the stage gave up: see below)
+  else if (c->svd_precondition == 3 && max_keep > 0 && ldt == m) {
+    int over = (int)std::ceil(sub_over * max_keep);
+    if (over < 64) over = 64;
+    r_sub = (max_keep + over + 63) / 64 * 64;
+    if (r_sub > (nn * 5) / 8 || r_sub <= 64) r_sub = 0;
+  }
   const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);
   const size_t t_d = ev((size_t)mm * nn);
-  const size_t need = sizeof(double) * (a_d + q_d + 2 * r_d + t_d + 8);
+  const size_t s_d = r_sub ? 2 * ev((size_t)nn * r_sub) + 2 * ev((size_t)mm * r_sub) : 0;
+  const size_t need = sizeof(double) * (a_d + q_d + 2 * r_d + t_d + s_d + 8);
   if (c->ws3_bytes < need) {
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->stream2));
@@ -1436,6 +1499,10 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   double* Rb = Qb + q_d;                   // R (nn x nn); R1 of the second pass
   double* Y = Rb + r_d;                    // sorted, normalised singular vectors from the Jacobi iteration (nn x nn)
   double* T = Y + r_d;                     // scratch: R^T, then theta V_k / U_k^T theta
+  SplitSub sb;
+  sb.r = r_sub;
+  sb.Yb = T + t_d; sb.Zb = sb.Yb + ev((size_t)nn * r_sub); sb.Wb = sb.Zb + ev((size_t)mm * r_sub);
+  sb.Bp = sb.Wb + ev((size_t)nn * r_sub);
   const double* Ap = (const double*)theta;
   int lda = ldt;
   if (transposed) {
@@ -1444,67 +1511,202 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   }
   const size_t qws = sizeof(double) * qr_ws_doubles(mm, nn), sws = tsvd_workspace_bytes(nn, nn);
   if (int rc = ensure_ws(c, (qws > sws ? qws : sws) + 256)) return rc;
-  if (int rc = qrpos_dispatch(c, mm, nn, Ap, lda, Qb, mm, Rb, nn, (double*)c->ws)) return rc;
-  // Double preconditioning (svd mode 2, Drmac-Veselic: "QR of R^T"): R^T = Q1 R1, Jacobi on the columns of R1^T.
-  // A' = Qb R = Qb R1^T Q1^T, and R1^T W = G = Y Sigma at convergence, so  A' = (Qb Y) Sigma (Q1 W)^T : the V-free
-  // iteration now yields the LEFT singular vectors Qb Y of the tall orientation (orthonormal to rounding as a product of
-  // orthonormal factors) and costs fewer sweeps (9 -> 6 at n = 512, 10 -> 7 at n = 1024 in the block-Jacobi model with
-  // exact inner solves; measured sweep counts: profiles/r02_svd_modes.log) for one extra n x n QRpos.
-  const bool dbl = c->svd_precondition == 2;
-  if (dbl) {
-    HIPCHK(transpose(Rb, nn, nn, nn, T, nn, c->stream));
-    if (int rc = qrpos_dispatch(c, nn, nn, T, nn, Y, nn, Rb, nn, (double*)c->ws)) return rc;     // Y = Q1 (not needed), Rb = R1
-  }
-  std::string err;
-  hipError_t e = tsvd(nn, nn, Rb, nn, Y, nn, (double*)S, nullptr, 1, max_keep, trunc_err, kept, disc_norm, c->ws, c->stream,
-                      &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->xstreams, 3, /*vfree=*/1);
-  if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
-  const int k = *kept;
-  REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");
-  if (!dbl) {
-    if (!transposed) {
-      // theta (m x n): Y_k = right singular vectors.  B = theta Y_k = U_k S_k ; AL C = QRpos(B) ; AR = Y_k^T
-      GemmArgs g = mk((const double*)theta, Y, T, m, k, n, ldt, nn, m);
-      HIPCHK(gemm_f64(g, c->stream));
-      if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
-      HIPCHK(transpose(Y, nn, n, k, (double*)AR, ldar, c->stream));
-    } else {
-      // theta (m x n), m < n: Y_k = left singular vectors = AL.  M = Y_k^T theta = S_k V_k^T ; C AR = LQpos(M)
-      HIPCHK(hipMemcpy2DAsync(AL, sizeof(double) * ldal, Y, sizeof(double) * nn, sizeof(double) * m, k,
-                              hipMemcpyDeviceToDevice, c->stream));
-      GemmArgs g = mk(Y, (const double*)theta, T, k, n, m, nn, ldt, k, 1, 0);
-      HIPCHK(gemm_f64(g, c->stream));
-      if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
+  const bool dbl = c->svd_precondition >= 2;
+  c->last_split_iters = 0; c->last_split_resid = 0.0; c->last_split_path = 0;
+
+  // attempt 0: the truncation-aware stage (when configured); attempt 1 (or the only one): the full iteration
+  double theta_nrm = 0.0;
+  int q_total = 0;
+  bool sub_ready = false;                  // sb.Yb holds a basis to continue from
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    const bool sub = r_sub > 0 && c->last_split_path != 2;
+    const int nc = sub ? r_sub : nn;       // columns of the matrix the Jacobi split runs on
+    const double* Bsrc = Ap;
+    int ldb = lda;
+    double te = trunc_err;
+    if (sub) {
+      if (!sub_ready) {
+        if (int rc = mpsk_vnrm2(c, (int64_t)m * n, theta, &theta_nrm)) return rc;
+        hipLaunchKernelGGL(split_fill_kernel, dim3(1024), dim3(256), 0, c->stream, sb.Yb, (int64_t)nn * r_sub, 0x5eedu);
+        int q0 = c->split_q_hint;
+        if (q0 < 2) q0 = 2;
+        if (int rc = split_iterate(c, mm, nn, Ap, lda, sb, q0)) return rc;
+        q_total += q0;
+        sub_ready = true;
+      }
+      // W = QRpos(Y) to working accuracy (R is not needed: Rb is scratch here), B' = A' W
+      if (int rc = qrpos_dispatch(c, nn, r_sub, sb.Yb, nn, sb.Wb, nn, Rb, r_sub, (double*)c->ws)) return rc;
+      GemmArgs gb = mk(Ap, sb.Wb, sb.Bp, mm, r_sub, nn, lda, nn, mm);
+      HIPCHK(gemm_f64(gb, c->stream));
+      Bsrc = sb.Bp; ldb = mm;
+      if (trunc_err > 0.0) {               // weight outside the subspace counts as discarded in the truncerr rule
+        double bn = 0.0;
+        if (int rc = mpsk_vnrm2(c, (int64_t)mm * r_sub, sb.Bp, &bn)) return rc;
+        const double out2 = std::max(theta_nrm * theta_nrm - bn * bn, 0.0);
+        te = std::sqrt(std::max(trunc_err * trunc_err - out2, 0.0));
+        if (te == 0.0) te = 1.0e-300;
+      }
     }
-  } else if (!transposed) {
-    // A' = theta: AL = Qb Y_k (left singular vectors).  M = AL^T theta = S_k V_k^T ; C AR = LQpos(M)
-    GemmArgs g = mk(Qb, Y, (double*)AL, m, k, n, mm, nn, ldal);
-    HIPCHK(gemm_f64(g, c->stream));
-    GemmArgs g2 = mk((const double*)AL, (const double*)theta, T, k, n, m, ldal, ldt, k, 1, 0);
-    HIPCHK(gemm_f64(g2, c->stream));
-    if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
-  } else {
-    // A' = theta^T (n x m): V_k = Qb Y_k = right singular vectors of theta.  B = theta V_k = U_k S_k ; AL C = QRpos(B) ; AR = V_k^T
-    double* Vk = At;                       // theta^T is no longer needed (n x k <= n x m)
-    GemmArgs g = mk(Qb, Y, Vk, n, k, m, mm, nn, n);
-    HIPCHK(gemm_f64(g, c->stream));
-    GemmArgs g2 = mk((const double*)theta, Vk, T, m, k, n, ldt, n, m);
-    HIPCHK(gemm_f64(g2, c->stream));
-    if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
-    HIPCHK(transpose(Vk, n, n, k, (double*)AR, ldar, c->stream));
+    if (int rc = qrpos_dispatch(c, mm, nc, Bsrc, ldb, Qb, mm, Rb, nc, (double*)c->ws)) return rc;
+    // Double preconditioning (svd mode 2, Drmac-Veselic: "QR of R^T"): R^T = Q1 R1, Jacobi on the columns of R1^T.
+    // A' = Qb R = Qb R1^T Q1^T, and R1^T W = G = Y Sigma at convergence, so  A' = (Qb Y) Sigma (Q1 W)^T : the V-free
+    // iteration now yields the LEFT singular vectors Qb Y of the tall orientation (orthonormal to rounding as a product of
+    // orthonormal factors) and costs fewer sweeps (9 -> 6 at n = 512, 10 -> 7 at n = 1024 in the block-Jacobi model with
+    // exact inner solves; measured sweep counts: profiles/r02_svd_modes.log) for one extra n x n QRpos.
+    if (dbl) {
+      HIPCHK(transpose(Rb, nc, nc, nc, T, nc, c->stream));
+      if (int rc = qrpos_dispatch(c, nc, nc, T, nc, Y, nc, Rb, nc, (double*)c->ws)) return rc;     // Y = Q1 (not needed), Rb = R1
+    }
+    std::string err;
+    hipError_t e = tsvd(nc, nc, Rb, nc, Y, nc, (double*)S, nullptr, 1, max_keep, te, kept, disc_norm, c->ws, c->stream,
+                        &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->xstreams, 3, /*vfree=*/1);
+    if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
+    const int k = *kept;
+    REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");
+    // the factor that carries theta: M' = U_k'^T A' (k x nn) as T (k x n) when A' = theta, as T^T (m x k) when A' = theta^T
+    double* Vk = At;                       // (transposed) theta^T is no longer needed once the iteration is over: see below
+    if (!dbl) {
+      if (!transposed) {
+        // theta (m x n): Y_k = right singular vectors.  B = theta Y_k = U_k S_k ; AL C = QRpos(B) ; AR = Y_k^T
+        GemmArgs g = mk((const double*)theta, Y, T, m, k, n, ldt, nn, m);
+        HIPCHK(gemm_f64(g, c->stream));
+        if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
+        HIPCHK(transpose(Y, nn, n, k, (double*)AR, ldar, c->stream));
+      } else {
+        // theta (m x n), m < n: Y_k = left singular vectors = AL.  M = Y_k^T theta = S_k V_k^T ; C AR = LQpos(M)
+        HIPCHK(hipMemcpy2DAsync(AL, sizeof(double) * ldal, Y, sizeof(double) * nn, sizeof(double) * m, k,
+                                hipMemcpyDeviceToDevice, c->stream));
+        GemmArgs g = mk(Y, (const double*)theta, T, k, n, m, nn, ldt, k, 1, 0);
+        HIPCHK(gemm_f64(g, c->stream));
+        if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
+      }
+      return MPSK_OK;
+    }
+    if (!transposed) {
+      // A' = theta: AL = Qb Y_k (left singular vectors).  M = AL^T theta = S_k V_k^T ; C AR = LQpos(M)
+      GemmArgs g = mk(Qb, Y, (double*)AL, m, k, nc, mm, nc, ldal);
+      HIPCHK(gemm_f64(g, c->stream));
+      GemmArgs g2 = mk((const double*)AL, (const double*)theta, T, k, n, m, ldal, ldt, k, 1, 0);
+      HIPCHK(gemm_f64(g2, c->stream));
+    } else {
+      // A' = theta^T (n x m): V_k = Qb Y_k = right singular vectors of theta.  B = theta V_k = U_k S_k ; AL C = QRpos(B) ; AR = V_k^T
+      if (sub) Vk = sb.Zb;                 // At (theta^T) is still needed if the check sends us back into the iteration
+      GemmArgs g = mk(Qb, Y, Vk, n, k, nc, mm, nc, n);
+      HIPCHK(gemm_f64(g, c->stream));
+      GemmArgs g2 = mk((const double*)theta, Vk, T, m, k, n, ldt, n, m);
+      HIPCHK(gemm_f64(g2, c->stream));
+    }
+    if (sub) {
+      // the check: rho = || M' (I - W W^T) ||_F / ||theta||_F  (M' = T, k x nn, or T^T = B, nn x k)
+      double* P1 = sb.Yb;                  // r x k (or k x r) scratch: Yb is rebuilt below if the iteration continues
+      double* Rs = transposed ? sb.Bp : sb.Zb;     // residual, k x nn / nn x k  (Bp / Zb are free now; Vk may live in Zb)
+      double rho = 0.0;
+      if (!transposed) {
+        GemmArgs p = mk(T, sb.Wb, P1, k, r_sub, nn, k, nn, k);                    // P1 = M' W            (k x r)
+        HIPCHK(gemm_f64(p, c->stream));
+        HIPCHK(hipMemcpyAsync(Rs, T, sizeof(double) * (size_t)k * nn, hipMemcpyDeviceToDevice, c->stream));
+        GemmArgs p2 = mk(P1, sb.Wb, Rs, k, nn, r_sub, k, nn, k, 0, 1);            // Rs = M' - P1 W^T
+        p2.alpha = -1.0; p2.beta = 1.0;
+        HIPCHK(gemm_f64(p2, c->stream));
+      } else {
+        GemmArgs p = mk(sb.Wb, T, P1, r_sub, k, nn, nn, nn, r_sub, 1, 0);         // P1 = W^T B           (r x k)
+        HIPCHK(gemm_f64(p, c->stream));
+        HIPCHK(hipMemcpyAsync(Rs, T, sizeof(double) * (size_t)k * nn, hipMemcpyDeviceToDevice, c->stream));
+        GemmArgs p2 = mk(sb.Wb, P1, Rs, nn, k, r_sub, nn, r_sub, nn);             // Rs = B - W P1
+        p2.alpha = -1.0; p2.beta = 1.0;
+        HIPCHK(gemm_f64(p2, c->stream));
+      }
+      if (int rc = mpsk_vnrm2(c, (int64_t)k * nn, Rs, &rho)) return rc;
+      rho = theta_nrm > 0.0 ? rho / theta_nrm : rho;
+      c->last_split_iters = q_total; c->last_split_resid = rho;
+      if (getenv("MPSK_SVD_DEBUG"))
+        fprintf(stderr, "[mpsk_tsplit] subspace stage: r = %d of %d, %d iterations, residual %.3e (tol %.1e), %d Jacobi sweeps\n",
+                r_sub, nn, q_total, rho, sub_tol, c->last_svd_sweeps);
+      // Ritz ratio sigma~_r / sigma~_k: an upper bound of the convergence factor sigma_{r+1} / sigma_k per half iteration
+      std::vector<double> hs(r_sub);
+      HIPCHK(hipMemcpyAsync(hs.data(), S, sizeof(double) * r_sub, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      const double ratio = (hs[k - 1] > 0.0 && std::isfinite(rho)) ? hs[r_sub - 1] / hs[k - 1] : 1.0;
+      if (!(rho <= sub_tol)) {
+        // not there: iterations still needed from the measured check value
+        int q_more = 1 << 20;
+        if (ratio < 0.97 && std::isfinite(rho)) q_more = (int)std::ceil(std::log(rho / (0.3 * sub_tol)) / (-2.0 * std::log(ratio)));
+        if (q_more < 2) q_more = 2;
+        // budget: one iteration ~ 4 n^2 r flops + two Cholesky chains; the full Jacobi iteration ~ 10 sweeps of 6 n^3 / ... :
+        // in measured terms (4096^2, r = 1536) 3.7 ms against ~200 ms, i.e. ~50 iterations; scaled by r / nn it stays ~40
+        const int q_cap = 40;
+        if (attempt >= 3 || q_total + q_more > q_cap) {
+          c->last_split_path = 2;          // fall through to the full iteration; flat spectra come in runs (the early
+          c->split_q_hint = 8;             // sweeps of a chain), so the next calls skip the stage: 4, 8, ... 64 of them
+          c->split_backoff = c->split_backoff ? std::min(2 * c->split_backoff, 64) : 4;
+          c->split_skip = c->split_backoff;
+          continue;
+        }
+        // continue from the r left Ritz vectors: Z = Qb Y (mm x r), Y <- orth1(A'^T Z), then q_more iterations
+        GemmArgs gz = mk(Qb, Y, sb.Zb, mm, r_sub, r_sub, mm, r_sub, mm);
+        HIPCHK(gemm_f64(gz, c->stream));
+        GemmArgs gy = mk(Ap, sb.Zb, sb.Wb, nn, r_sub, mm, lda, mm, nn, 1, 0);
+        HIPCHK(gemm_f64(gy, c->stream));
+        HIPCHK(cholqr1_orth(nn, r_sub, sb.Wb, nn, sb.Yb, nn, (double*)c->ws, c->d_flag, c->stream));
+        if (int rc = split_iterate(c, mm, nn, Ap, lda, sb, q_more)) return rc;
+        q_total += q_more + 1;
+        continue;
+      }
+      c->last_split_path = 1;
+      c->split_backoff = 0;
+      // next call's first guess (neighbouring bonds of a chain have similar spectra): the count this spectrum needs from a
+      // random start, ratio^(2 q) <= tol / 10, but not more than this call took
+      {
+        int qn = ratio < 0.97 ? (int)std::ceil(std::log(0.1 * sub_tol) / (2.0 * std::log(ratio))) : q_total;
+        if (qn > q_total) qn = q_total;
+        if (qn < 3) qn = 3;
+        c->split_q_hint = qn;
+      }
+      // S: the r leading values are Ritz values of the converged subspace; the rest is not computed
+      if (nn > r_sub)
+        hipLaunchKernelGGL(split_fill_nan_kernel, dim3((nn - r_sub + 255) / 256), dim3(256), 0, c->stream, (double*)S + r_sub, nn - r_sub);
+      // discarded weight: || theta - AL M ||_F formed directly (theta_nrm^2 - |M|^2 cancels when little is discarded);
+      // Qb (mm x nn) is free once AL / V_k exist
+      double* Dm = Qb;
+      HIPCHK(hipMemcpy2DAsync(Dm, sizeof(double) * m, theta, sizeof(double) * ldt, sizeof(double) * m, n, hipMemcpyDeviceToDevice, c->stream));
+      if (!transposed) {
+        GemmArgs gd = mk((const double*)AL, T, Dm, m, n, k, ldal, k, m);
+        gd.alpha = -1.0; gd.beta = 1.0;
+        HIPCHK(gemm_f64(gd, c->stream));
+      } else {
+        GemmArgs gd = mk(T, Vk, Dm, m, n, k, m, n, m, 0, 1);                      // theta - (theta V_k) V_k^T
+        gd.alpha = -1.0; gd.beta = 1.0;
+        HIPCHK(gemm_f64(gd, c->stream));
+      }
+      if (int rc = mpsk_vnrm2(c, (int64_t)m * n, Dm, disc_norm)) return rc;
+    }
+    if (!transposed) {
+      if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
+    } else {
+      if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
+      HIPCHK(transpose(Vk, n, n, k, (double*)AR, ldar, c->stream));
+    }
+    return MPSK_OK;
   }
-  return MPSK_OK;
+  return fail(MPSK_ERR_HIP, "mpsk_tsplit: internal error (no path finished)");
 }
 
 int mpsk_ctx_set_svd_mode(mpsk_ctx* c, int precondition) {
   REQUIRE(c, "ctx is NULL");
-  REQUIRE(precondition >= 0 && precondition <= 2, "svd mode must be 0 (none), 1 (QR), 2 (QR + QR of R^T, mpsk_tsplit)");
+  REQUIRE(precondition >= 0 && precondition <= 3, "svd mode must be 0 (none), 1 (QR), 2 (QR + QR of R^T), 3 (2 + truncation-aware mpsk_tsplit)");
   c->svd_precondition = precondition;
   return MPSK_OK;
 }
 int mpsk_ctx_svd_stats(mpsk_ctx* c, int* last_sweeps) {
   REQUIRE(c && last_sweeps, "NULL argument");
   *last_sweeps = c->last_svd_sweeps;
+  return MPSK_OK;
+}
+int mpsk_ctx_split_stats(mpsk_ctx* c, int* path, int* iterations, double* residual) {
+  REQUIRE(c, "ctx is NULL");
+  if (path) *path = c->last_split_path;
+  if (iterations) *iterations = c->last_split_iters;
+  if (residual) *residual = c->last_split_resid;
   return MPSK_OK;
 }
 

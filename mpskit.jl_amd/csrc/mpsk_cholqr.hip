@@ -866,6 +866,17 @@ hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int 
   return hipGetLastError();
 }
 
+// One SHIFTED CholeskyQR pass, Q = X R^-1 with X^T X + s I = R^T R (the published shift: positive definite for every X).
+// Not a QR factorization to working accuracy (cond(Q) is only bounded by ~1 / sqrt(s_rel), R is not returned): the cheap
+// re-conditioning step between two multiplications of the subspace iteration of mpsk_tsplit (svd mode 3), where only
+// span(Q) = span(X) matters and one Cholesky chain replaces three.  X and Q must not overlap.  Enqueues only.
+hipError_t cholqr1_orth(int m, int n, const double* X, int ldx, double* Q, int ldq, double* ws, int* d_flag, hipStream_t s) {
+  const CqBufs b = cq_bufs(m, n, ws);
+  hipError_t e;
+  if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
+  return cq_pass(m, n, b.npad, X, ldx, Q, ldq, b.R1, b.Rinv, b.T, /*shifted=*/true, false, d_flag, s, 1.0);
+}
+
 hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                    int* d_flag, int* flag_out, hipStream_t s, double shift_scale) {
   hipError_t e = cholqr3_enqueue(m, n, A, lda, Q, ldq, R, ldr, ws, d_flag, flag_out, s, shift_scale);

@@ -339,14 +339,28 @@ __device__ __forceinline__ double sv_dpp(double x) {
   return __hiloint2double(hi, lo);
 }
 
-__host__ __device__ constexpr int eig2_lo(int t, int pk) {
-  const int a = (pk == 0) ? J2 - 1 : (t + pk) % (J2 - 1), b = (pk == 0) ? t : (t + (J2 - 1) - pk) % (J2 - 1);
-  return a < b ? a : b;
+// Order of the 63 steps of one inner sweep over the 64 columns of a pair (block A = columns 0-31, block B = 32-63):
+//   steps 0-30   INTRA: two independent 32-column round robins side by side (16 + 16 pairs per step; B runs its round robin
+//                16 steps ahead of A's, which keeps the four teams of a 32-lane LDS access group 8 columns apart);
+//   steps 31-62  CROSS: pair k = (k, 32 + (k + t) mod 32): every column of A against every column of B.
+// A block leaves a pair with its 32 columns mutually orthogonal, so on its next visit the intra rotations are second-order
+// small: the kernel skips steps 0-30 outright when the measured intra cosines are far below the cross ones (see `intra_ratio`).
+constexpr int EIG2_NI = J2 / 2 - 1;          // 31 intra steps
+__host__ __device__ constexpr int eig2_pair(int t, int pk, bool hi) {
+  int a = 0, b = 0;
+  if (t < EIG2_NI) {
+    const int k = pk & 15, off = (pk & 16) ? J2 / 2 : 0;
+    const int tt = (pk & 16) ? (t + 16) % EIG2_NI : t;
+    a = off + ((k == 0) ? EIG2_NI : (tt + k) % EIG2_NI);
+    b = off + ((k == 0) ? tt : (tt + EIG2_NI - k) % EIG2_NI);
+  } else {
+    a = pk;
+    b = J2 / 2 + (pk + (t - EIG2_NI)) % (J2 / 2);
+  }
+  return hi ? (a < b ? b : a) : (a < b ? a : b);
 }
-__host__ __device__ constexpr int eig2_hi(int t, int pk) {
-  const int a = (pk == 0) ? J2 - 1 : (t + pk) % (J2 - 1), b = (pk == 0) ? t : (t + (J2 - 1) - pk) % (J2 - 1);
-  return a < b ? b : a;
-}
+__host__ __device__ constexpr int eig2_lo(int t, int pk) { return eig2_pair(t, pk, false); }
+__host__ __device__ constexpr int eig2_hi(int t, int pk) { return eig2_pair(t, pk, true); }
 // wave 4: the 32 rotations of step T on the register-resident rows of W (every index a compile-time constant).  The
 // (c, s) pairs are broadcast LDS reads (all lanes, one address), fetched in groups of 8 one group ahead of their use;
 // scheduling barriers keep the compiler from clustering all 32 reads up front (128 more live registers: it spilled W).
@@ -441,25 +455,26 @@ __device__ __forceinline__ void eig2_r_step(double (*Ms)[J2 + 1], double* __rest
 // wave 4's side of one inner sweep: phase ST applies the rotations of step ST - 1 (published by waves 0-3 during phase
 // ST - 1) and joins the phase's barrier.  Waves 0-3 run their own, rolled loop with the SAME number of barriers
 // (s_barrier counts arrivals, not program locations).
-template <int ST>
+template <int ST, int END>
 __device__ __forceinline__ void eig2_w_phases(double (*cs)[2 * 32], double (&w)[J2]) {
-  if constexpr (ST < J2) {
+  if constexpr (ST < END) {
     if constexpr (ST >= 1 && MPSK_EIG2_DIAG != 1) eig2_w_apply<ST - 1>(w, cs[(ST - 1) & 1]);
     __syncthreads();
-    eig2_w_phases<ST + 1>(cs, w);
+    eig2_w_phases<ST + 1, END>(cs, w);
   }
 }
 
 __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double* __restrict__ Mpart, int Q,
                                                                    double* __restrict__ Wout, double tol,
                                                                    unsigned long long* __restrict__ flag, int inner_sweeps,
+                                                                   double intra_ratio,
                                                                    unsigned long long* __restrict__ dbg) {
   __shared__ double Ms[J2][J2 + 1];
   __shared__ double Ws[J2][J2 + 1];
   __shared__ double P[2][4][J2];
   __shared__ double dsc[J2], dinv[J2];
   __shared__ __attribute__((aligned(16))) double cs[2][2 * 32];     // (c, s) of pair k of a step at [buf][2k], [2k + 1]
-  __shared__ double red[4];
+  __shared__ double red[2][4];
   __shared__ int any_rot;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -489,7 +504,8 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
   EIG2_STAMP(1);
   // symmetrise and measure in ONE pass: the thread that owns (i, j), i < j, also owns (j, i); max |cos|^2 through the
   // hardware reciprocal (the convergence decision has 1e-8 of slack), one square root per workgroup at the end
-  double mx = 0.0;
+  // (separately for column pairs inside one block and across the two blocks: see eig2_pair)
+  double mx = 0.0, mxi = 0.0;
   if (rw) {
     for (int e = tid; e < J2 * J2; e += 256) {
       const int i = e % J2, j = e / J2;
@@ -497,16 +513,24 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
         const double a = 0.5 * (Ms[i][j] + Ms[j][i]);
         const double dd = Ms[i][i] * Ms[j][j];
         const double r2 = (a == 0.0) ? 0.0 : (dd > 0.0 ? a * a * __builtin_amdgcn_rcp(dd) : 1.0);
-        mx = fmax(mx, r2);
+        if ((i < J2 / 2) == (j < J2 / 2)) mxi = fmax(mxi, r2); else mx = fmax(mx, r2);
         Ms[i][j] = a;
         Ms[j][i] = a;
       }
     }
-    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
-    if (lane == 0) red[wave] = mx;
+    for (int off = 32; off > 0; off >>= 1) {
+      mx = fmax(mx, __shfl_xor(mx, off, 64));
+      mxi = fmax(mxi, __shfl_xor(mxi, off, 64));
+    }
+    if (lane == 0) { red[0][wave] = mx; red[1][wave] = mxi; }
   }
   __syncthreads();
-  mx = sqrt(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
+  mx = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+  mxi = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+  // intra steps skipped on the first inner sweep when the blocks are still orthogonal inside relative to the coupling
+  // between them (cos^2 ratio; uniform over the workgroup).  Whatever is skipped here is measured again on the next visit.
+  const bool skip_intra = mxi <= intra_ratio * mx;
+  mx = sqrt(fmax(mx, mxi));
   if (tid == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(mx));
   double* Wp = Wout + (size_t)p * J2 * J2;
   if (mx <= tol) {                           // (uniform over the workgroup)
@@ -596,7 +620,8 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
       if (tid == 0) any_rot = 0;
       __syncthreads();
       int rotated = 0;
-      for (int st = 0; st < J2; ++st) {      // phase st: step st (< 63); wave 4 applies step st - 1 meanwhile
+      const int st0 = (sweep == 0 && skip_intra) ? EIG2_NI : 0;
+      for (int st = st0; st < J2; ++st) {    // phase st: step st (< 63); wave 4 applies step st - 1 meanwhile
         if (st < J2 - 1 && MPSK_EIG2_DIAG != 2) eig2_r_step(Ms, cs[st & 1], st, pk, pj, &rotated);
         __syncthreads();
       }
@@ -612,7 +637,12 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
     for (int c = 0; c < J2; ++c) w[c] = (c == lane) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
       __syncthreads();
-      eig2_w_phases<0>(cs, w);
+      if (!(sweep == 0 && skip_intra)) {
+        eig2_w_phases<0, EIG2_NI>(cs, w);
+        if (MPSK_EIG2_DIAG != 1) eig2_w_apply<EIG2_NI - 1>(w, cs[(EIG2_NI - 1) & 1]);
+      }
+      __syncthreads();                       // phase 31
+      eig2_w_phases<EIG2_NI + 1, J2>(cs, w);
       __syncthreads();
       if (!any_rot) break;
       __syncthreads();
@@ -686,12 +716,15 @@ __global__ __launch_bounds__(EIG2_THREADS) void jacobi_eig2_kernel(const double*
 // MPSK_SVD_STAMPS=1: pair 0 of every launch leaves six real-time stamps (100 MHz) here; printed with MPSK_SVD_DEBUG
 static unsigned long long* g_eig2_dbg = nullptr;
 static const int g_svd_eig = getenv("MPSK_SVD_EIG") ? atoi(getenv("MPSK_SVD_EIG")) : 2;
+// intra-block steps are skipped when max intra cos^2 <= this * max cross cos^2 (0 = never skip)
+static const double g_svd_intra = getenv("MPSK_SVD_INTRA") ? atof(getenv("MPSK_SVD_INTRA")) : 1.0e-2;
 static inline void launch_eig(int npairs, hipStream_t s, const double* Mpart, int Q, double* Wb, double tol,
                               unsigned long long* flag, int inner_sweeps) {
   if (g_svd_eig == 1)
     hipLaunchKernelGGL(jacobi_eig_kernel, dim3(npairs), dim3(256), 0, s, Mpart, Q, Wb, tol, flag, inner_sweeps);
   else
-    hipLaunchKernelGGL(jacobi_eig2_kernel, dim3(npairs), dim3(EIG2_THREADS), 0, s, Mpart, Q, Wb, tol, flag, inner_sweeps, g_eig2_dbg);
+    hipLaunchKernelGGL(jacobi_eig2_kernel, dim3(npairs), dim3(EIG2_THREADS), 0, s, Mpart, Q, Wb, tol, flag, inner_sweeps,
+                       npairs > 1 ? g_svd_intra : 0.0, g_eig2_dbg);
 }
 
 // sigma2[j] = sum_r G[r, j]^2   (one workgroup per column)

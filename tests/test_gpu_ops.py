@@ -370,7 +370,7 @@ def test_tsvd_plain_mode_matches_preconditioned(be, m, n):
             assert np.abs(U.T @ U - np.eye(k)).max() < 1e-12 and np.abs(Vh @ Vh.T - np.eye(k)).max() < 1e-12
             assert relerr((U * S) @ Vh, A) < 1e-12
     finally:
-        be.set_svd_mode(True)
+        be.set_svd_mode(3)          # the ctx default
 
 
 def test_tsvd_graded_and_rank_deficient_preconditioned(be):
@@ -403,7 +403,7 @@ def test_tsvd_graded_and_rank_deficient_preconditioned(be):
             be.tsvd(be.upload(A), max_keep=128)
         sw_plain = be.svd_sweeps()
     finally:
-        be.set_svd_mode(True)
+        be.set_svd_mode(3)          # the ctx default
     assert sw_pre <= 12 and sw_pre < sw_plain == 40, (sw_pre, sw_plain)
     # exact rank deficiency: rank 100 of 256
     B = rng.standard_normal((384, 100)) @ rng.standard_normal((100, 256))
@@ -480,11 +480,13 @@ def test_qrlq_pair(be, m, n):
     assert relerr(Q1, Qs) < 1e-12 and relerr(L2, Ls) < 1e-11 and relerr(Q2, Qls) < 1e-10
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("m,n,k", [(512, 384, 100), (384, 512, 100), (1024, 1024, 256), (200, 130, 0), (1536, 1280, 300)])
 def test_tsplit(be, m, n, k, mode):
     """mpsk_tsplit (V-free Jacobi + rebuilt factor): al, ar isometries, al c ar = the optimal rank-k truncation of theta
-    (same singular values / discarded norm as numpy), c triangular, for both orientations and a graded spectrum."""
+    (same singular values / discarded norm as numpy), c triangular, for both orientations and a graded spectrum.
+    Mode 3 (default): the truncation-aware stage (subspace iteration + Jacobi on r = k + max(64, k/2) columns) must have
+    produced the result (path 1) and meets the same bounds."""
     rng = np.random.default_rng(m + 3 * n + k)
     r = min(m, n)
     Uo, _ = np.linalg.qr(rng.standard_normal((m, r)))
@@ -494,8 +496,11 @@ def test_tsplit(be, m, n, k, mode):
     be.set_svd_mode(mode)          # 1: QR-preconditioned, 2: QR + QR of R^T (left singular vectors come out of the iteration)
     try:
         al, c, ar, S, disc = be.tsplit(be.upload(A), max_keep=k)
+        st = be.split_stats()
     finally:
-        be.set_svd_mode(1)
+        be.set_svd_mode(3)
+    assert st["path"] == (1 if (mode == 3 and k > 0) else 0)
+    assert mode != 3 or k == 0 or st["residual"] <= 1e-12
     kk = k if k > 0 else r
     al, c, ar = be.download(al), be.download(c), be.download(ar)
     assert al.shape == (m, kk) and c.shape == (kk, kk) and ar.shape == (kk, n)
@@ -506,6 +511,61 @@ def test_tsplit(be, m, n, k, mode):
     assert np.abs(al @ c @ ar - best).max() < 1e-12
     assert np.abs(np.linalg.svd(c, compute_uv=False) - s[:kk]).max() < 1e-13
     assert np.abs(np.tril(c, -1)).max() < 1e-13 or np.abs(np.triu(c, 1)).max() < 1e-13
+
+
+def test_tsplit_truncation_aware_stage_gives_up_on_flat_spectra_and_backs_off(be):
+    """svd mode 3 on a spectrum without decay behind the cut (uniform random theta: sigma_{r+1} / sigma_k ~ 0.9): the
+    check fails, the predicted iteration count is over budget, the call falls through to the full iteration (path 2) and
+    returns the same result as mode 2; the next calls skip the stage (path 0) -- flat spectra come in runs."""
+    rng = np.random.default_rng(5)
+    n, k = 768, 128
+    A = rng.random((n, n)) - 0.5
+    sref = np.linalg.svd(A, compute_uv=False)
+    import mpskit_jl_amd as mk
+    be2 = mk.Backend(0)                       # own ctx: the back-off counter is per ctx
+    dA = be2.upload(A)
+    paths = []
+    for _ in range(3):
+        al, c, ar, S, disc = be2.tsplit(dA, max_keep=k)
+        paths.append(be2.split_stats()["path"])
+        assert np.abs(S - sref[:k]).max() < 1e-12 * sref[0]
+        assert abs(disc - np.linalg.norm(sref[k:])) < 1e-11 * sref[0]
+        a_, c_, r_ = be2.download(al), be2.download(c), be2.download(ar)
+        assert np.abs(a_.T @ a_ - np.eye(k)).max() < 1e-12 and np.abs(r_ @ r_.T - np.eye(k)).max() < 1e-12
+        assert abs(np.linalg.norm(A - a_ @ c_ @ r_) - np.linalg.norm(sref[k:])) < 1e-11 * sref[0]
+    be2.close()
+    assert paths == [2, 0, 0]
+
+
+def test_tsplit_truncation_aware_rank_deficient_and_truncerr(be):
+    """svd mode 3 where the subspace is wider than the rank of theta (rank 150, r = 192: the early two-site sweeps of a
+    growing chain) and with the truncerr rule deciding the cut: same kept rank, values and discarded weight as mode 2."""
+    rng = np.random.default_rng(9)
+    m, n, rank = 640, 512, 150
+    s = np.logspace(0, -7, rank)
+    Uo, _ = np.linalg.qr(rng.standard_normal((m, rank)))
+    Vo, _ = np.linalg.qr(rng.standard_normal((n, rank)))
+    A = (Uo * s) @ Vo.T
+    dA = be.upload(A)
+    res = {}
+    for mode in (2, 3):
+        be.set_svd_mode(mode)
+        try:
+            res[mode] = [be.tsplit(dA, max_keep=100), be.tsplit(dA, max_keep=128, trunc_err=1e-4)]
+            path = be.split_stats()["path"]
+        finally:
+            be.set_svd_mode(3)
+        assert path == (1 if mode == 3 else 0)
+    for (a2, c2, r2, S2, d2), (a3, c3, r3, S3, d3) in zip(res[2], res[3]):
+        assert len(S2) == len(S3) and np.abs(S2 - S3).max() < 1e-13
+        assert abs(d2 - d3) < 1e-13
+        k = len(S3)
+        A3 = be.download(a3) @ be.download(c3) @ be.download(r3)
+        best = (Uo[:, :k] * s[:k]) @ Vo[:, :k].T
+        assert np.abs(A3 - best).max() < 1e-12
+        assert np.abs(be.download(a3).T @ be.download(a3) - np.eye(k)).max() < 1e-12
+    assert len(res[3][1][3]) < 128                      # truncerr(1e-4) cut below max_keep: tail norm <= 1e-4
+    assert np.linalg.norm(s[len(res[3][1][3]):]) <= 1e-4 < np.linalg.norm(s[len(res[3][1][3]) - 1:])
 
 
 @pytest.mark.parametrize("m,n", [(48, 40), (40, 48), (64, 64)])
