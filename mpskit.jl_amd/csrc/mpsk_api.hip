@@ -1445,16 +1445,25 @@ struct SplitSub {             // state of the subspace stage across refinements
   double *Yb = nullptr, *Zb = nullptr, *Wb = nullptr, *Bp = nullptr;   // nn x r, mm x r, nn x r, mm x r
 };
 
+// one re-conditioning pass X -> Q (span preserved): rounding-level shift first, the published shift if a pivot broke down
+static int split_orth1(mpsk_ctx* c, int m, int r, const double* X, double* Q) {
+  HIPCHK(cholqr1_orth(m, r, X, m, Q, m, (double*)c->ws, c->d_flag, c->stream, c->qr_shift_fast));
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (flag) HIPCHK(cholqr1_orth(m, r, X, m, Q, m, (double*)c->ws, c->d_flag, c->stream, 1.0));
+  return MPSK_OK;
+}
 // q iterations  Y <- orth1(A'^T orth1(A' Y))  starting from Yb (nn x r); result in Yb.  Zb / Wb / Bp are scratch.
 static int split_iterate(mpsk_ctx* c, int mm, int nn, const double* Ap, int lda, const SplitSub& sb, int q) {
   const int r = sb.r;
   for (int i = 0; i < q; ++i) {
     GemmArgs g = mk(Ap, sb.Yb, sb.Zb, mm, r, nn, lda, nn, mm);
     HIPCHK(gemm_f64(g, c->stream));
-    HIPCHK(cholqr1_orth(mm, r, sb.Zb, mm, sb.Bp, mm, (double*)c->ws, c->d_flag, c->stream));
+    if (int rc = split_orth1(c, mm, r, sb.Zb, sb.Bp)) return rc;
     GemmArgs g2 = mk(Ap, sb.Bp, sb.Wb, nn, r, mm, lda, mm, nn, 1, 0);
     HIPCHK(gemm_f64(g2, c->stream));
-    HIPCHK(cholqr1_orth(nn, r, sb.Wb, nn, sb.Yb, nn, (double*)c->ws, c->d_flag, c->stream));
+    if (int rc = split_orth1(c, nn, r, sb.Wb, sb.Yb)) return rc;
   }
   return MPSK_OK;
 }
@@ -1515,8 +1524,8 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   c->last_split_iters = 0; c->last_split_resid = 0.0; c->last_split_path = 0;
 
   // attempt 0: the truncation-aware stage (when configured); attempt 1 (or the only one): the full iteration
-  double theta_nrm = 0.0;
-  int q_total = 0;
+  double theta_nrm = 0.0, rho_prev = 0.0;
+  int q_total = 0, q_prev = 0, n_checks = 0;
   bool sub_ready = false;                  // sb.Yb holds a basis to continue from
   for (int attempt = 0; attempt < 8; ++attempt) {
     const bool sub = r_sub > 0 && c->last_split_path != 2;
@@ -1619,19 +1628,26 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
       if (int rc = mpsk_vnrm2(c, (int64_t)k * nn, Rs, &rho)) return rc;
       rho = theta_nrm > 0.0 ? rho / theta_nrm : rho;
       c->last_split_iters = q_total; c->last_split_resid = rho;
-      if (getenv("MPSK_SVD_DEBUG"))
-        fprintf(stderr, "[mpsk_tsplit] subspace stage: r = %d of %d, %d iterations, residual %.3e (tol %.1e), %d Jacobi sweeps\n",
-                r_sub, nn, q_total, rho, sub_tol, c->last_svd_sweeps);
+      ++n_checks;
       // Ritz ratio sigma~_r / sigma~_k: an upper bound of the convergence factor sigma_{r+1} / sigma_k per half iteration
       std::vector<double> hs(r_sub);
       HIPCHK(hipMemcpyAsync(hs.data(), S, sizeof(double) * r_sub, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       const double ratio = (hs[k - 1] > 0.0 && std::isfinite(rho)) ? hs[r_sub - 1] / hs[k - 1] : 1.0;
+      if (getenv("MPSK_SVD_DEBUG"))
+        fprintf(stderr, "[mpsk_tsplit] subspace stage: r = %d of %d, %d iterations, residual %.3e (tol %.1e), Ritz ratio s_r / s_k = %.3f, %d Jacobi sweeps\n",
+                r_sub, nn, q_total, rho, sub_tol, ratio, c->last_svd_sweeps);
       if (!(rho <= sub_tol)) {
         // not there: iterations still needed from the measured check value
+        // (a Ritz ratio taken before convergence UNDERestimates sigma_{r+1} / sigma_k -- sigma~_r is still far below
+        // sigma_r --, so from the second check on the OBSERVED decay of the check value per iteration is used instead)
         int q_more = 1 << 20;
-        if (ratio < 0.97 && std::isfinite(rho)) q_more = (int)std::ceil(std::log(rho / (0.3 * sub_tol)) / (-2.0 * std::log(ratio)));
+        double fac = ratio < 0.97 ? ratio * ratio : 1.0;              // error factor per iteration
+        if (rho_prev > 0.0 && rho < rho_prev && q_total > q_prev) fac = std::pow(rho / rho_prev, 1.0 / (q_total - q_prev));
+        else fac = std::sqrt(fac);                                    // first check: assume half the predicted rate
+        if (fac < 0.95 && std::isfinite(rho)) q_more = (int)std::ceil(std::log(0.1 * sub_tol / rho) / std::log(fac));
         if (q_more < 2) q_more = 2;
+        rho_prev = rho; q_prev = q_total;
         // budget: one iteration ~ 4 n^2 r flops + two Cholesky chains; the full Jacobi iteration ~ 10 sweeps of 6 n^3 / ... :
         // in measured terms (4096^2, r = 1536) 3.7 ms against ~200 ms, i.e. ~50 iterations; scaled by r / nn it stays ~40
         const int q_cap = 40;
@@ -1647,21 +1663,17 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
         HIPCHK(gemm_f64(gz, c->stream));
         GemmArgs gy = mk(Ap, sb.Zb, sb.Wb, nn, r_sub, mm, lda, mm, nn, 1, 0);
         HIPCHK(gemm_f64(gy, c->stream));
-        HIPCHK(cholqr1_orth(nn, r_sub, sb.Wb, nn, sb.Yb, nn, (double*)c->ws, c->d_flag, c->stream));
+        if (int rc = split_orth1(c, nn, r_sub, sb.Wb, sb.Yb)) return rc;
         if (int rc = split_iterate(c, mm, nn, Ap, lda, sb, q_more)) return rc;
         q_total += q_more + 1;
         continue;
       }
       c->last_split_path = 1;
       c->split_backoff = 0;
-      // next call's first guess (neighbouring bonds of a chain have similar spectra): the count this spectrum needs from a
-      // random start, ratio^(2 q) <= tol / 10, but not more than this call took
-      {
-        int qn = ratio < 0.97 ? (int)std::ceil(std::log(0.1 * sub_tol) / (2.0 * std::log(ratio))) : q_total;
-        if (qn > q_total) qn = q_total;
-        if (qn < 3) qn = 3;
-        c->split_q_hint = qn;
-      }
+      // next call's first guess (neighbouring bonds of a chain have similar spectra): what this one took, one less when
+      // the first check already passed with two digits to spare (a failed check costs a second Jacobi stage, ~15 iterations'
+      // worth; an iteration too many costs one)
+      c->split_q_hint = (n_checks == 1 && rho <= 1.0e-2 * sub_tol && q_total > 3) ? q_total - 1 : q_total;
       // S: the r leading values are Ritz values of the converged subspace; the rest is not computed
       if (nn > r_sub)
         hipLaunchKernelGGL(split_fill_nan_kernel, dim3((nn - r_sub + 255) / 256), dim3(256), 0, c->stream, (double*)S + r_sub, nn - r_sub);

@@ -867,14 +867,19 @@ hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int 
 }
 
 // One SHIFTED CholeskyQR pass, Q = X R^-1 with X^T X + s I = R^T R (the published shift: positive definite for every X).
-// Not a QR factorization to working accuracy (cond(Q) is only bounded by ~1 / sqrt(s_rel), R is not returned): the cheap
+// Not a QR factorization to working accuracy (orthogonality ~ u cond(X)^2, R is not returned): the cheap
 // re-conditioning step between two multiplications of the subspace iteration of mpsk_tsplit (svd mode 3), where only
 // span(Q) = span(X) matters and one Cholesky chain replaces three.  X and Q must not overlap.  Enqueues only.
-hipError_t cholqr1_orth(int m, int n, const double* X, int ldx, double* Q, int ldq, double* ws, int* d_flag, hipStream_t s) {
+// shift_scale: fraction of the published shift.  The published shift (1.0) never breaks down but DAMPS every direction
+// with sigma_i < ~1e-4 sigma_max (Q's singular value there is sigma_i / sqrt(sigma_i^2 + s)): repeated over the iterations
+// the small wanted directions of a two-site tensor (sigma_k / sigma_1 ~ 1e-6) fade away.  The caller therefore passes the
+// rounding-level scale first and repeats the pass with 1.0 when *d_flag comes back non-zero (pivot breakdown).
+hipError_t cholqr1_orth(int m, int n, const double* X, int ldx, double* Q, int ldq, double* ws, int* d_flag, hipStream_t s,
+                        double shift_scale) {
   const CqBufs b = cq_bufs(m, n, ws);
   hipError_t e;
   if ((e = hipMemsetAsync(d_flag, 0, sizeof(int), s)) != hipSuccess) return e;
-  return cq_pass(m, n, b.npad, X, ldx, Q, ldq, b.R1, b.Rinv, b.T, /*shifted=*/true, false, d_flag, s, 1.0);
+  return cq_pass(m, n, b.npad, X, ldx, Q, ldq, b.R1, b.Rinv, b.T, /*shifted=*/true, false, d_flag, s, shift_scale);
 }
 
 hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,

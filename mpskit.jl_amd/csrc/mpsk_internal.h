@@ -143,7 +143,8 @@ hipError_t cholqr3(int m, int n, const double* A, int lda, double* Q, int ldq, d
                    int* d_flag, int* flag_out, hipStream_t s, double shift_scale = 1.0);
 hipError_t cholqr_robust(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                          int* d_flag, int* flag_out, hipStream_t s);
-hipError_t cholqr1_orth(int m, int n, const double* X, int ldx, double* Q, int ldq, double* ws, int* d_flag, hipStream_t s);
+hipError_t cholqr1_orth(int m, int n, const double* X, int ldx, double* Q, int ldq, double* ws, int* d_flag, hipStream_t s,
+                        double shift_scale);
 hipError_t cholqr3_enqueue(int m, int n, const double* A, int lda, double* Q, int ldq, double* R, int ldr, double* ws,
                            int* d_flag, int* flag_out, hipStream_t s, double shift_scale = 1.0);
 hipError_t cholqr3_finalize(int m, int n, double* Q, int ldq, double* R, int ldr, double* ws, int* d_flag,

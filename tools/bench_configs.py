@@ -65,7 +65,7 @@ def c4sweep(be, L=16, D=256, nsweeps=2):
     Jacobi sweep counts on the theta tensors a real run produces (graded Schmidt spectra)."""
     H = mk.hubbard(1.0, 4.0, be=be)
     psi = mk.FiniteMPS.random(L, 4, D, np.random.default_rng(3), be=be)
-    stat = {"svd_s": 0.0, "svd_n": 0, "sweeps": [], "eig_s": 0.0}
+    stat = {"svd_s": 0.0, "svd_n": 0, "sweeps": [], "eig_s": 0.0, "paths": [], "iters": []}
     orig_tsvd, orig_fp = be.tsplit, alg.fixedpoint
 
     def tsvd_timed(*a, **k):
@@ -73,6 +73,12 @@ def c4sweep(be, L=16, D=256, nsweeps=2):
         out = orig_tsvd(*a, **k)
         sync(); stat["svd_s"] += time.perf_counter() - t0; stat["svd_n"] += 1
         stat["sweeps"].append(be.svd_sweeps())
+        st = be.split_stats()
+        stat["paths"].append(st["path"]); stat["iters"].append(st["iterations"])
+        if os.environ.get("C4_VERBOSE"):
+            sv = out[3]
+            print(f"  split {a[0].shape} keep {len(sv)}: {(time.perf_counter() - t0) * 1e3:7.1f} ms  path {st['path']} iters {st['iterations']:2d} "
+                  f"resid {st['residual']:.1e}  jacobi sweeps {be.svd_sweeps():2d}  s_k/s_1 {sv[-1] / sv[0]:.1e}  disc {out[4]:.2e}", flush=True)
         return out
 
     def fp_timed(*a, **k):
@@ -85,7 +91,7 @@ def c4sweep(be, L=16, D=256, nsweeps=2):
     try:
         for it in range(nsweeps):
             for k in stat:
-                stat[k] = [] if k == "sweeps" else 0
+                stat[k] = [] if k in ("sweeps", "paths", "iters") else 0
             q0 = be.qr_stats()
             sync(); t0 = time.perf_counter()
             psi, envs, eps = mk.find_groundstate(psi, H, mk.DMRG2(tol=1e-14, maxiter=1, trunc_dim=D,
@@ -95,6 +101,8 @@ def c4sweep(be, L=16, D=256, nsweeps=2):
             sw = stat["sweeps"]
             print(f"c4sweep Hubbard L={L} D={D} sweep {it + 1}: {dt:.2f} s  eigsolve {stat['eig_s']:.2f} s  tsvd {stat['svd_s']:.2f} s "
                   f"({stat['svd_n']} calls, Jacobi sweeps min/mean/max {min(sw)}/{np.mean(sw):.1f}/{max(sw)}), "
+                  f"split paths full/subspace/gave-up {stat['paths'].count(0)}/{stat['paths'].count(1)}/{stat['paths'].count(2)}, "
+                  f"subspace iterations mean {np.mean([i for i, p in zip(stat['iters'], stat['paths']) if p == 1] or [0]):.1f}, "
                   f"qr +{ {k: q1[k] - q0[k] for k in q1} }, max bond {max(psi.bond_dims())}", flush=True)
     finally:
         be.tsplit, alg.fixedpoint = orig_tsvd, orig_fp
