@@ -537,6 +537,33 @@ def test_tsplit_truncation_aware_stage_gives_up_on_flat_spectra_and_backs_off(be
     assert paths == [2, 0, 0]
 
 
+def test_tsplit_dominance_probe_rejects_an_unconverged_subspace(be):
+    """The last line of defence of svd mode 3: with the residual check disabled and a single subspace iteration (test hook
+    MPSK_SPLIT_DEBUG_SKIP_CHECK), the kept subspace is far from the dominant one, the remainder theta - AL M contains
+    directions above the cut, and the power-iteration probe must send the call to the full iteration (path 2) -- the
+    result is then the exact one."""
+    import os
+    import mpskit_jl_amd as mk
+    rng = np.random.default_rng(21)
+    n, k = 640, 128
+    Uo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Vo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.logspace(0, -2, n)                  # slow decay: one iteration leaves O(1) errors
+    A = (Uo * s) @ Vo.T
+    be2 = mk.Backend(0)
+    os.environ["MPSK_SPLIT_DEBUG_SKIP_CHECK"] = "1"
+    try:
+        al, c, ar, S, disc = be2.tsplit(be2.upload(A), max_keep=k)
+        st = be2.split_stats()
+    finally:
+        del os.environ["MPSK_SPLIT_DEBUG_SKIP_CHECK"]
+    assert st["path"] == 2 and st["iterations"] == 1
+    assert np.abs(S - s[:k]).max() < 1e-13 and abs(disc - np.linalg.norm(s[k:])) < 1e-13
+    best = (Uo[:, :k] * s[:k]) @ Vo[:, :k].T
+    assert np.abs(be2.download(al) @ be2.download(c) @ be2.download(ar) - best).max() < 1e-12
+    be2.close()
+
+
 def test_tsplit_truncation_aware_rank_deficient_and_truncerr(be):
     """svd mode 3 where the subspace is wider than the rank of theta (rank 150, r = 192: the early two-site sweeps of a
     growing chain) and with the truncerr rule deciding the cut: same kept rank, values and discarded weight as mode 2."""

@@ -33,8 +33,9 @@ if [ "$PART" = all ] || [ "$PART" = core ]; then
 fi
 if [ "$PART" = all ] || [ "$PART" = configs ]; then
   timeout -k 10 300 python tools/bench_site.py > $O/${TAG}_site_breakdown.log 2>&1
-  timeout -k 10 1100 python tools/bench_configs.py c2 c3 c4 tsvd c4sweep:16:1024 c4sweep:64:1024:1 ctdvp:32:128 ctdvp:24:512 > $O/${TAG}_other_configs.log 2>&1
+  timeout -k 10 1100 python tools/bench_configs.py c2 c3 c4 tsvd c4sweep:16:1024 c4sweep:64:1024:3 ctdvp:32:128 ctdvp:24:512 > $O/${TAG}_other_configs.log 2>&1
   timeout -k 10 400 python tools/svd_probe.py 1024,2048,4096 graded6 graded12 uniform > $O/${TAG}_svd_modes.log 2>&1
+  timeout -k 10 300 python tools/split_probe.py 3 > $O/${TAG}_split_probe.log 2>&1
   timeout -k 10 200 python tools/bench_cplx.py 128 256 512 1024 > $O/${TAG}_bench_cplx.log 2>&1
   (timeout -k 10 100 python tools/qr_only.py 2048 1024; timeout -k 10 100 python tools/qr_only.py 768 256; timeout -k 10 100 python tools/qr_only.py 4096 4096 3; timeout -k 10 200 python tools/qr_fallback_cost.py) > $O/${TAG}_qr_only.log 2>&1
   MPSK_BENCH_PROF=1 timeout -k 10 300 python tools/bench_dac.py 1024,2,5 2048,2,5 1024,4,6 256,3,5 512,2,3 > $O/${TAG}_bench_dac.log 2>&1

@@ -1,4 +1,4 @@
-"""Two-site split timing / sweep counts per preconditioning mode (1: QR, 2: QR + QR of R^T) and spectrum.
+"""Two-site split timing / sweep counts per svd mode (1: QR, 2: QR + QR of R^T, 3: 2 + truncation-aware stage) and spectrum.
 usage: svd_probe.py n[,n...] [kind ...]     kinds: graded6 graded12 uniform colgraded"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +26,7 @@ for n in sizes:
         M = make(n, kind)
         A = mk.DTensor(M.T.contiguous().flatten(), (n, n))
         sref = torch.linalg.svdvals(M).cpu().numpy()
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             be.set_svd_mode(mode)
             be.tsplit(A, max_keep=n // 4)
             torch.cuda.synchronize()
@@ -41,4 +41,4 @@ for n in sizes:
             rec = float(((alT @ cT @ arT) - M).square().sum().sqrt())
             print(f"tsplit {n}x{n} {kind:9s} mode {mode}: {dt:7.1f} ms  sweeps {be.svd_sweeps():2d}  |S - Sref| {np.abs(S - sref[:k]).max():.1e}  "
                   f"orth {orth:.1e}  |rec - theta| - disc {abs(rec - disc):.1e}", flush=True)
-be.set_svd_mode(1)
+be.set_svd_mode(3)
