@@ -317,7 +317,10 @@ def main():
     # reference's default eigensolver Arnoldi(tol = 1e-12, krylovdim = 30, maxiter = 100, eager) (defaults.jl:33,
     # dmrg.jl:17) instead of the fixed budget -- independent of --steps
     to_tol = None
-    if not args.no_tolerance_sweep and args.tol_sweeps > 0:
+    # (N = 1 only: a tolerance-mode solve takes data-dependent host decisions per Krylov step; the ranks of a sharded sweep
+    #  hold bit-identical scalars by construction, but that lock-step has never met N > 1 on hardware -- the scaling runs
+    #  time the fixed-budget sweeps, which have no data-dependent control flow)
+    if not args.no_tolerance_sweep and args.tol_sweeps > 0 and world == 1:
         nmv = {"n": 0}
         orig_eig = krylov.eigsolve_sr
 
