@@ -260,10 +260,11 @@ end
 
 # ---- the two-site split  al, c, ar = tsvd!(ac2; trunc) ; normalize!(c)   (dmrg.jl:96-104, tdvp.jl:124-126) ----
 # c comes back triangular instead of diagonal (al*c*ar is the same truncated theta, al / ar isometries): no rotation
-# accumulation in the Jacobi sweeps.  S holds the kept Schmidt values.
+# accumulation in the Jacobi sweeps.  S is a min(m, n) buffer (include/mpsk.h): the kept Schmidt values lead it; with the
+# truncation-aware default (svd mode 3) only the first r = truncdim + max(64, truncdim / 2) entries are computed, NaN behind.
 function tsplit(theta::ROCTensor{2}; truncdim::Int=0, truncerr::Float64=0.0)
     m, n = theta.dims; k = min(m, n); kmax = truncdim > 0 ? min(k, truncdim) : k
-    AL, Cm, AR, S = ROCTensor((m, kmax)), ROCTensor((kmax, kmax)), ROCTensor((kmax, n)), ROCTensor((kmax,))
+    AL, Cm, AR, S = ROCTensor((m, kmax)), ROCTensor((kmax, kmax)), ROCTensor((kmax, n)), ROCTensor((k,))
     kept = Ref{Cint}(0); disc = Ref{Float64}(0)
     check(ccall((:mpsk_tsplit, libmpsk[]), Cint,
         (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ref{Cint}, Ref{Float64}),
