@@ -1489,7 +1489,8 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
     int over = (int)std::ceil(sub_over * max_keep);
     if (over < 64) over = 64;
     r_sub = (max_keep + over + 63) / 64 * 64;
-    if (r_sub > (nn * 5) / 8 || r_sub <= 64) r_sub = 0;
+    static const double sub_frac = getenv("MPSK_SPLIT_MAXFRAC") ? atof(getenv("MPSK_SPLIT_MAXFRAC")) : 0.625;
+    if (r_sub > (int)(nn * sub_frac) || r_sub <= 64) r_sub = 0;
   }
   const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);
   const size_t t_d = ev((size_t)mm * nn);
