@@ -1355,7 +1355,9 @@ int mpsk_tsvd(mpsk_ctx* c, int m, int n, const void* theta, int ldt, void* U, in
     const bool dbl = c->svd_precondition >= 2;
     const size_t a_d = transposed ? ev((size_t)mm * nn) : 0, q_d = ev((size_t)mm * nn), r_d = ev((size_t)nn * nn);
     const size_t x_d = dbl ? 3 * r_d : 0;                              // Q1 / R^T, U'', Vh'' of the double preconditioning
-    const size_t qws = sizeof(double) * qr_ws_doubles(mm, nn), sws = tsvd_workspace_bytes(nn, nn);
+    // (the workspace of a factorization is NOT monotone in its shape: the in-step solve / Gram of the small regime adds
+    //  CQ_GS npad^2 doubles, so the square second QR can need more than the tall first one)
+    const size_t qws = sizeof(double) * std::max(qr_ws_doubles(mm, nn), qr_ws_doubles(nn, nn)), sws = tsvd_workspace_bytes(nn, nn);
     if (int rc = ensure_ws(c, sizeof(double) * (a_d + q_d + r_d + x_d) + (qws > sws ? qws : sws) + 256)) return rc;
     double* At = (double*)c->ws;
     double* Qb = At + a_d;
@@ -1457,13 +1459,23 @@ static int split_orth1(mpsk_ctx* c, int m, int r, const double* X, double* Q) {
 // q iterations  Y <- orth1(A'^T orth1(A' Y))  starting from Yb (nn x r); result in Yb.  Zb / Wb / Bp are scratch.
 static int split_iterate(mpsk_ctx* c, int mm, int nn, const double* Ap, int lda, const SplitSub& sb, int q) {
   const int r = sb.r;
+  const bool trace = getenv("MPSK_SPLIT_TRACE") != nullptr;
+  auto stage = [&](const char* name, int i) {
+    if (!trace) return;
+    hipError_t e_ = hipStreamSynchronize(c->stream);
+    fprintf(stderr, "[mpsk_tsplit]   iteration %d %-12s %s\n", i, name, hipGetErrorString(e_)); fflush(stderr);
+  };
   for (int i = 0; i < q; ++i) {
     GemmArgs g = mk(Ap, sb.Yb, sb.Zb, mm, r, nn, lda, nn, mm);
     HIPCHK(gemm_f64(g, c->stream));
+    stage("Z = A' Y", i);
     if (int rc = split_orth1(c, mm, r, sb.Zb, sb.Bp)) return rc;
+    stage("orth1(Z)", i);
     GemmArgs g2 = mk(Ap, sb.Bp, sb.Wb, nn, r, mm, lda, mm, nn, 1, 0);
     HIPCHK(gemm_f64(g2, c->stream));
+    stage("Y = A'^T Z", i);
     if (int rc = split_orth1(c, nn, r, sb.Wb, sb.Yb)) return rc;
+    stage("orth1(Y)", i);
   }
   return MPSK_OK;
 }
@@ -1519,7 +1531,13 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
     HIPCHK(transpose((const double*)theta, ldt, m, n, At, mm, c->stream));
     Ap = At; lda = mm;
   }
-  const size_t qws = sizeof(double) * qr_ws_doubles(mm, nn), sws = tsvd_workspace_bytes(nn, nn);
+  // every factorization below runs in c->ws.  Its size is NOT monotone in the shape (the in-step solve / Gram of the small
+  // regime adds CQ_GS npad^2 doubles: a 1280 x 1280 QRpos needs 3x the workspace of a 2048 x 2048 one), so take the maximum
+  // over all shapes this call can factor: A' (mm x nn), R^T (nn x nn) and, with the subspace stage, Y (nn x r), A'Y / B'
+  // (mm x r), R_B^T (r x r)
+  size_t qwd = std::max(qr_ws_doubles(mm, nn), qr_ws_doubles(nn, nn));
+  if (r_sub) qwd = std::max(std::max(qwd, qr_ws_doubles(nn, r_sub)), std::max(qr_ws_doubles(mm, r_sub), qr_ws_doubles(r_sub, r_sub)));
+  const size_t qws = sizeof(double) * qwd, sws = tsvd_workspace_bytes(nn, nn);
   if (int rc = ensure_ws(c, (qws > sws ? qws : sws) + 256)) return rc;
   const bool dbl = c->svd_precondition >= 2;
   c->last_split_iters = 0; c->last_split_resid = 0.0; c->last_split_path = 0;
@@ -1528,6 +1546,9 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   // test hook (tests/test_gpu_ops.py): one iteration and the residual check waved through, so that the dominance probe is
   // the only line of defence -- it must then send the call to the full iteration
   const bool dbg_skip_check = getenv("MPSK_SPLIT_DEBUG_SKIP_CHECK") != nullptr;
+  const bool dbg_trace = getenv("MPSK_SPLIT_TRACE") != nullptr;      // sync + one stderr line per stage (fault localisation)
+#define SPLIT_STAGE(name) do { if (dbg_trace) { hipError_t e_ = hipStreamSynchronize(c->stream); \
+    fprintf(stderr, "[mpsk_tsplit] stage %-28s %s\n", name, hipGetErrorString(e_)); fflush(stderr); } } while (0)
   double theta_nrm = 0.0, rho_prev = 0.0;
   int q_total = 0, q_prev = 0, n_checks = 0;
   bool sub_ready = false;                  // sb.Yb holds a basis to continue from
@@ -1545,14 +1566,17 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
         if (q0 < 2) q0 = 2;
         if (dbg_skip_check) q0 = 1;
         if (int rc = split_iterate(c, mm, nn, Ap, lda, sb, q0)) return rc;
+        SPLIT_STAGE("iterate");
         q_total += q0;
         sub_ready = true;
       }
       // W = QRpos(Y) to working accuracy (R is not needed: Rb is scratch here), B' = A' W
       if (int rc = qrpos_dispatch(c, nn, r_sub, sb.Yb, nn, sb.Wb, nn, Rb, r_sub, (double*)c->ws)) return rc;
+      SPLIT_STAGE("QRpos(Y)");
       GemmArgs gb = mk(Ap, sb.Wb, sb.Bp, mm, r_sub, nn, lda, nn, mm);
       HIPCHK(gemm_f64(gb, c->stream));
       Bsrc = sb.Bp; ldb = mm;
+      SPLIT_STAGE("B' = A' W");
       if (trunc_err > 0.0) {               // weight outside the subspace counts as discarded in the truncerr rule
         double bn = 0.0;
         if (int rc = mpsk_vnrm2(c, (int64_t)mm * r_sub, sb.Bp, &bn)) return rc;
@@ -1562,6 +1586,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
       }
     }
     if (int rc = qrpos_dispatch(c, mm, nc, Bsrc, ldb, Qb, mm, Rb, nc, (double*)c->ws)) return rc;
+    SPLIT_STAGE("QRpos(B')");
     // Double preconditioning (svd mode 2, Drmac-Veselic: "QR of R^T"): R^T = Q1 R1, Jacobi on the columns of R1^T.
     // A' = Qb R = Qb R1^T Q1^T, and R1^T W = G = Y Sigma at convergence, so  A' = (Qb Y) Sigma (Q1 W)^T : the V-free
     // iteration now yields the LEFT singular vectors Qb Y of the tall orientation (orthonormal to rounding as a product of
@@ -1570,6 +1595,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
     if (dbl) {
       HIPCHK(transpose(Rb, nc, nc, nc, T, nc, c->stream));
       if (int rc = qrpos_dispatch(c, nc, nc, T, nc, Y, nc, Rb, nc, (double*)c->ws)) return rc;     // Y = Q1 (not needed), Rb = R1
+      SPLIT_STAGE("QRpos(R^T)");
     }
     std::string err;
     hipError_t e = tsvd(nc, nc, Rb, nc, Y, nc, (double*)S, nullptr, 1, max_keep, te, kept, disc_norm, c->ws, c->stream,
@@ -1577,6 +1603,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
     if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
     const int k = *kept;
     REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");
+    SPLIT_STAGE("jacobi");
     // the factor that carries theta: M' = U_k'^T A' (k x nn) as T (k x n) when A' = theta, as T^T (m x k) when A' = theta^T
     double* Vk = At;                       // (transposed) theta^T is no longer needed once the iteration is over: see below
     if (!dbl) {
@@ -1631,6 +1658,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
         HIPCHK(gemm_f64(p2, c->stream));
       }
       if (int rc = mpsk_vnrm2(c, (int64_t)k * nn, Rs, &rho)) return rc;
+      SPLIT_STAGE("check");
       rho = theta_nrm > 0.0 ? rho / theta_nrm : rho;
       if (dbg_skip_check) rho = 0.0;
       c->last_split_iters = q_total; c->last_split_resid = rho;
@@ -1697,6 +1725,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
         HIPCHK(gemm_f64(gd, c->stream));
       }
       if (int rc = mpsk_vnrm2(c, (int64_t)m * n, Dm, disc_norm)) return rc;
+      SPLIT_STAGE("remainder");
       // dominance probe.  The check above certifies that span(AL) is INVARIANT (a singular subspace of theta); that it is
       // the DOMINANT one rests on the random start having a component along every leading direction (probability one, and
       // r - k >= 64 spare columns).  Cheap insurance against the measure-zero case: a few power iterations on the
@@ -1718,6 +1747,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
           GemmArgs gx = mk(Dm, yv, xv, n, 1, m, m, m, n, 1, 0);
           HIPCHK(gemm_f64(gx, c->stream));
         }
+        SPLIT_STAGE("probe");
         if (est > 1.02 * hs[k - 1] + 1.0e-13 * theta_nrm) {
           if (getenv("MPSK_SVD_DEBUG"))
             fprintf(stderr, "[mpsk_tsplit] dominance probe: |D x| = %.6e above S[k-1] = %.6e -> full iteration\n", est, hs[k - 1]);
@@ -1726,15 +1756,18 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
         }
       }
     }
+    SPLIT_STAGE("before LQpos / QRpos");
     if (!transposed) {
       if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
     } else {
       if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
       HIPCHK(transpose(Vk, n, n, k, (double*)AR, ldar, c->stream));
     }
+    SPLIT_STAGE("done");
     return MPSK_OK;
   }
   return fail(MPSK_ERR_HIP, "mpsk_tsplit: internal error (no path finished)");
+#undef SPLIT_STAGE
 }
 
 int mpsk_ctx_set_svd_mode(mpsk_ctx* c, int precondition) {

@@ -537,6 +537,34 @@ def test_tsplit_truncation_aware_stage_gives_up_on_flat_spectra_and_backs_off(be
     assert paths == [2, 0, 0]
 
 
+@pytest.mark.parametrize("m,n,k,mode", [(3200, 1024, 256, 2), (3200, 1024, 256, 3), (2048, 2048, 800, 3), (1024, 3200, 256, 3)])
+def test_tsplit_workspace_of_the_inner_factorizations_on_a_fresh_ctx(m, n, k, mode):
+    """The QRpos workspace is not monotone in the shape (the small regime's in-step solve / Gram adds CQ_GS npad^2 doubles):
+    mpsk_tsplit / mpsk_tsvd must size the ctx workspace for the LARGEST of their inner factorizations, not for the first.
+    On a fresh ctx (nothing grew the workspace before) a tall theta whose R^T is in the small regime, and a 2048^2 split whose
+    1216-column Jacobi stage is (a GPU memory fault before the fix), must simply work."""
+    import mpskit_jl_amd as mk
+    rng = np.random.default_rng(m + n + k)
+    r = min(m, n)
+    Uo, _ = np.linalg.qr(rng.standard_normal((m, r)))
+    Vo, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    s = np.logspace(0, -6, r)
+    A = (Uo * s) @ Vo.T
+    be2 = mk.Backend(0)
+    try:
+        be2.set_svd_mode(mode)
+        al, c, ar, S, disc = be2.tsplit(be2.upload(A), max_keep=k)
+        assert be2.split_stats()["path"] == (1 if mode == 3 else 0)
+        assert np.abs(S - s[:k]).max() < 1e-13 and abs(disc - np.linalg.norm(s[k:])) < 1e-13
+        al, c, ar = be2.download(al), be2.download(c), be2.download(ar)
+        assert np.abs(al.T @ al - np.eye(k)).max() < 1e-12 and np.abs(ar @ ar.T - np.eye(k)).max() < 1e-12
+        assert np.abs(al @ c @ ar - (Uo[:, :k] * s[:k]) @ Vo[:, :k].T).max() < 1e-12
+        U, Sd, Vh, kept, _ = be2.tsvd(be2.upload(A), max_keep=k)          # mpsk_tsvd has the same two factorizations
+        assert kept == k and np.abs(be2.download(Sd).ravel()[:k] - s[:k]).max() < 1e-13
+    finally:
+        be2.close()
+
+
 def test_tsplit_dominance_probe_rejects_an_unconverged_subspace(be):
     """The last line of defence of svd mode 3: with the residual check disabled and a single subspace iteration (test hook
     MPSK_SPLIT_DEBUG_SKIP_CHECK), the kept subspace is far from the dominant one, the remainder theta - AL M contains

@@ -16,6 +16,7 @@ torch.cuda.synchronize(); t0 = time.time()
 for _ in range(3):
     al, c, ar, S, disc = be.tsplit(A, max_keep=n // 2)
 torch.cuda.synchronize()
+dt = (time.time() - t0) / 3 * 1e3
 sref = torch.linalg.svdvals(M).cpu().numpy()
 import numpy as np
-print(f"tsplit {n} -> {n // 2} {kind} mode {mode}: {(time.time() - t0) / 3 * 1e3:.1f} ms, sweeps {be.svd_sweeps()}, {be.split_stats()}, |S - Sref| {np.abs(S - sref[:n // 2]).max():.1e}", flush=True)
+print(f"tsplit {n} -> {n // 2} {kind} mode {mode}: {dt:.1f} ms, sweeps {be.svd_sweeps()}, {be.split_stats()}, |S - Sref| {np.abs(S - sref[:n // 2]).max():.1e}", flush=True)
