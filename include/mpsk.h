@@ -86,7 +86,7 @@ int mpsk_ctx_qr_retries(mpsk_ctx* ctx, long* n_retry);
  * mpsk_tsvd: 15 -> 10 sweeps on graded 4096^2 tensors for one more n x n QRpos).  mpsk_ctx_svd_stats returns the number of
  * Jacobi sweeps of the last mpsk_tsvd / mpsk_tsplit.
  * 3 (default) = mode 2, and mpsk_tsplit becomes TRUNCATION-AWARE when max_keep > 0 and r = max_keep + max(64, max_keep / 2) (rounded
- * up to 64) is at most 5/8 of min(m, n): a randomized subspace iteration on the GEMM core finds the dominant r-dimensional
+ * up to 64; max_keep / 4 if that is too wide) is at most 5/8 of min(m, n): a randomized subspace iteration on the GEMM core finds the dominant r-dimensional
  * subspace, the Jacobi split runs on r columns instead of min(m, n), and the result is accepted only after a CHECK -- the
  * part of the kept triplets outside the iterated subspace, || U_k^T theta (I - W W^T) ||_F <= 1e-12 ||theta||_F
  * (MPSK_SPLIT_TOL) -- otherwise the iteration continues or the call falls through to mode 2 (flat spectra).  Same AL / C / AR

@@ -481,7 +481,8 @@ def test_qrlq_pair(be, m, n):
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
-@pytest.mark.parametrize("m,n,k", [(512, 384, 100), (384, 512, 100), (1024, 1024, 256), (200, 130, 0), (1536, 1280, 300)])
+@pytest.mark.parametrize("m,n,k", [(512, 384, 100), (384, 512, 100), (1024, 1024, 256), (200, 130, 0), (1536, 1280, 300),
+                                   (1024, 1024, 512)])          # the last: keep HALF (d = 2 chains), stage with r = 5n/8
 def test_tsplit(be, m, n, k, mode):
     """mpsk_tsplit (V-free Jacobi + rebuilt factor): al, ar isometries, al c ar = the optimal rank-k truncation of theta
     (same singular values / discarded norm as numpy), c triangular, for both orientations and a graded spectrum.
