@@ -65,7 +65,9 @@ struct mpsk_ctx {
   int dtype = MPSK_F64;         // scalar type of the slice-less entry points (mpsk_ctx_set_dtype)
   int last_svd_sweeps = 0;
   int split_skip = 0, split_backoff = 0;           // calls that skip the stage after it gave up
-  int split_q_hint = 8;         // subspace iterations the next truncation-aware mpsk_tsplit starts with (what the last one needed)
+  // subspace iterations the next truncation-aware mpsk_tsplit of the same (min(m, n), r) starts with: what the last one needed
+  // (the bonds near the ends of a chain have other shapes and other spectra than the bulk; 8 for a shape not seen yet)
+  std::map<std::pair<int, int>, int> split_q_hint;
   int last_split_iters = 0, last_split_path = 0;   // path: 0 full iteration (mode <= 2 / not applicable), 1 subspace stage, 2 stage gave up -> full
   double last_split_resid = 0.0;
   int svd_precondition = 3;     // mpsk_ctx_set_svd_mode: 0 plain, 1 QR-preconditioned, 2 QR + QR of R^T (mpsk_tsplit V-free, mpsk_tsvd with accumulated rotations), 3 = 2 + truncation-aware mpsk_tsplit
@@ -1568,7 +1570,8 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
       if (!sub_ready) {
         if (int rc = mpsk_vnrm2(c, (int64_t)m * n, theta, &theta_nrm)) return rc;
         hipLaunchKernelGGL(split_fill_kernel, dim3(1024), dim3(256), 0, c->stream, sb.Yb, (int64_t)nn * r_sub, 0x5eedu);
-        int q0 = c->split_q_hint;
+        const auto hit = c->split_q_hint.find(std::make_pair(nn, r_sub));
+        int q0 = hit == c->split_q_hint.end() ? 8 : hit->second;
         if (q0 < 2) q0 = 2;
         if (dbg_skip_check) q0 = 1;
         if (int rc = split_iterate(c, mm, nn, Ap, lda, sb, q0)) return rc;
@@ -1693,7 +1696,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
         const int q_cap = 40;
         if (attempt >= 3 || q_total + q_more > q_cap) {
           c->last_split_path = 2;          // fall through to the full iteration; flat spectra come in runs (the early
-          c->split_q_hint = 8;             // sweeps of a chain), so the next calls skip the stage: 4, 8, ... 64 of them
+          c->split_q_hint.erase(std::make_pair(nn, r_sub));   // sweeps of a chain), so the next calls skip the stage: 4, 8, ... 64 of them
           c->split_backoff = c->split_backoff ? std::min(2 * c->split_backoff, 64) : 4;
           c->split_skip = c->split_backoff;
           continue;
@@ -1713,7 +1716,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
       // next call's first guess (neighbouring bonds of a chain have similar spectra): what this one took, one less when
       // the first check already passed with two digits to spare (a failed check costs a second Jacobi stage, ~15 iterations'
       // worth; an iteration too many costs one)
-      c->split_q_hint = (n_checks == 1 && rho <= 1.0e-2 * sub_tol && q_total > 3) ? q_total - 1 : q_total;
+      c->split_q_hint[std::make_pair(nn, r_sub)] = (n_checks == 1 && rho <= 1.0e-2 * sub_tol && q_total > 3) ? q_total - 1 : q_total;
       // S: the r leading values are Ritz values of the converged subspace; the rest is not computed
       if (nn > r_sub)
         hipLaunchKernelGGL(split_fill_nan_kernel, dim3((nn - r_sub + 255) / 256), dim3(256), 0, c->stream, (double*)S + r_sub, nn - r_sub);
