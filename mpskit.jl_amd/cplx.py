@@ -263,20 +263,40 @@ def split_two_site(be, theta: DTensor, trunc_dim=0, trunc_err=0.0, rng=None):
     Dl2, d1, Dr2, d2 = theta.shape
     m2, n2 = Dl2 * d1, Dr2 * d2
     th = theta.reshape(m2, n2)
-    U, S, Vh, kept, _ = be.tsvd(th, max_keep=2 * trunc_dim if trunc_dim > 0 else 0, trunc_err=trunc_err)
-    s = be.download(S)
-    kmax = len(s)
-    K2 = min(kept + (kept & 1), kmax - (kmax & 1))
-    tol_c = 1e-8
-    lo = K2
-    while lo > 0 and abs(s[lo - 1] - s[K2 - 1]) <= tol_c * s[K2 - 1] + 1e-14 * s[0]:
-        lo -= 1
-    hi = K2
-    while hi < kmax and abs(s[hi] - s[K2 - 1]) <= tol_c * s[K2 - 1] + 1e-14 * s[0]:
-        hi += 1
-    lo -= lo & 1
-    hi += hi & 1
-    hi = min(hi, kmax)
+    fast = None
+    PAD = 16                                   # singular values / vectors looked at beyond the cut (cluster detection)
+    if trunc_dim > 0 and trunc_err == 0.0 and min(m2, n2) > 64 and 2 * trunc_dim + PAD <= min(m2, n2):
+        # truncdim scheme: the truncation-aware two-site split (mpsk_tsplit, svd mode 3: subspace iteration + Jacobi on
+        # ~1.5 k columns, checked) delivers the 2 k + PAD leading left singular vectors and values -- all this routine
+        # needs -- instead of the full decomposition with accumulated rotations (mpsk_tsvd)
+        U, _, _, s, _ = be.tsplit(th, max_keep=2 * trunc_dim + PAD)
+        kmax, K2 = len(s), 2 * trunc_dim
+        fast = be.norm(th) ** 2                # |theta|^2 = sum of ALL squared singular values
+    if fast is None:
+        U, S, Vh, kept, _ = be.tsvd(th, max_keep=2 * trunc_dim if trunc_dim > 0 else 0, trunc_err=trunc_err)
+        s = be.download(S)
+        kmax = len(s)
+        K2 = min(kept + (kept & 1), kmax - (kmax & 1))
+    def cluster(s, K2, kmax):
+        """[lo, hi): the (even-aligned) run of singular values equal to s[K2 - 1] to 1e-8 -- the cluster the cut may split"""
+        tol_c = 1e-8
+        lo = K2
+        while lo > 0 and abs(s[lo - 1] - s[K2 - 1]) <= tol_c * s[K2 - 1] + 1e-14 * s[0]:
+            lo -= 1
+        hi = K2
+        while hi < kmax and abs(s[hi] - s[K2 - 1]) <= tol_c * s[K2 - 1] + 1e-14 * s[0]:
+            hi += 1
+        return lo - (lo & 1), min(hi + (hi & 1), kmax)
+
+    lo, hi = cluster(s, K2, kmax)
+    if fast is not None and hi >= kmax and kmax < min(m2, n2):
+        # the cluster at the cut runs past the vectors the fast path computed: take the full decomposition instead
+        U, S, Vh, kept, _ = be.tsvd(th, max_keep=2 * trunc_dim, trunc_err=0.0)
+        s = be.download(S)
+        kmax = len(s)
+        K2 = min(kept + (kept & 1), kmax - (kmax & 1))
+        fast = None
+        lo, hi = cluster(s, K2, kmax)
     B = be.empty(m2, K2)                                       # orthonormal basis of the kept subspace
     if hi == K2:
         be.copy2d(m2, K2, U.ptr, m2, B.ptr, m2)
@@ -298,7 +318,7 @@ def split_two_site(be, theta: DTensor, trunc_dim=0, trunc_err=0.0, rng=None):
     ar = be.empty(K2, d2, Dr2)
     for s2 in range(d2):                                       # arm[k, (b, s2)] -> ar[k, s2, b]
         be.copy2d(K2, Dr2, arm.ptr + 8 * s2 * K2 * Dr2, K2, ar.ptr + 8 * s2 * K2, K2 * d2)
-    tot2 = float(np.sum(s * s))
+    tot2 = float(np.sum(s * s)) if fast is None else fast
     kept2 = be.norm(c) ** 2
     disc = float(np.sqrt(max(tot2 - kept2, 0.0) / 2.0))
     return al.reshape(Dl2, d1, K2), c, ar, s[0:K2:2].copy(), disc

@@ -192,3 +192,36 @@ def test_complex_states_in_changebonds_and_finite_excited_gpu(be):
     (same body as the host-logic test on the CPU stand-in: tests/test_host_logic_cpu.py)."""
     from test_host_logic_cpu import test_complex_states_in_changebonds_and_finite_excited as body
     body(be)
+
+
+@pytest.mark.parametrize("m,n,k", [(192, 160, 40), (160, 192, 40), (256, 256, 64)])
+def test_structured_split_through_the_truncation_aware_tsplit(be, m, n, k):
+    """cplx.split_two_site at sizes where it takes mpsk_tsplit (2 k + 16 leading vectors; svd mode 3 runs its subspace
+    stage on the doubled spectrum of the embedding) instead of the full mpsk_tsvd: al / ar are EMBEDDED isometries, the kept
+    Schmidt values are the complex singular values, al c ar is the optimal rank-k truncation (numpy complex SVD); and a
+    degenerate pair of complex singular values across the cut (a 4-fold cluster in the embedding) still gives a structured,
+    optimal split."""
+    from mpskit_jl_amd import cplx
+    rng = np.random.default_rng(m + n)
+    r = min(m, n)
+    for degenerate in (False, True):
+        U, _ = np.linalg.qr(rng.standard_normal((m, r)) + 1j * rng.standard_normal((m, r)))
+        V, _ = np.linalg.qr(rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r)))
+        sv = np.logspace(0, -5, r)
+        if degenerate:
+            sv[k] = sv[k - 1]
+        th = (U * sv) @ V.conj().T
+        E = cplx.embed(th).reshape(2 * m, 1, 2 * n, 1)              # theta_E[(2 Dl), d1, (2 Dr), d2] with d1 = d2 = 1
+        al, c, ar, S, disc = cplx.split_two_site(be, be.upload(E), trunc_dim=k)
+        assert be.split_stats()["path"] in (0, 1)
+        A, Cm, B = be.download(al), be.download(c), be.download(ar)
+        K2 = 2 * k
+        assert A.shape == (2 * m, 1, K2) and B.shape == (K2, 1, 2 * n)
+        A2, B2 = A.reshape(2 * m, K2), B.reshape(K2, 2 * n)
+        assert np.abs(A2.T @ A2 - np.eye(K2)).max() < 1e-12 and np.abs(B2 @ B2.T - np.eye(K2)).max() < 1e-12
+        assert cplx.structure_defect(A2) < 1e-12 and cplx.structure_defect(B2) < 1e-12 and cplx.structure_defect(Cm) < 1e-12
+        assert np.abs(S - sv[:k]).max() < 1e-12
+        rec = cplx.extract(A2 @ Cm @ B2)
+        best_err = np.linalg.norm(sv[k:])
+        assert abs(np.linalg.norm(th - rec) - best_err) < 1e-11
+        assert abs(disc - best_err) < 1e-11
