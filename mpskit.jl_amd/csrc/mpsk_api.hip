@@ -1609,6 +1609,10 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
     std::string err;
     hipError_t e = tsvd(nc, nc, Rb, nc, Y, nc, (double*)S, nullptr, 1, max_keep, te, kept, disc_norm, c->ws, c->stream,
                         &err, &c->last_svd_sweeps, nullptr, 0, 0, 0, c->xstreams, 3, /*vfree=*/1);
+    if (e == hipErrorNotReady && sub) {      // the Jacobi stage on B' did not converge: nothing is lost, take the full iteration
+      c->last_split_path = 2;
+      continue;
+    }
     if (e != hipSuccess) return fail(MPSK_ERR_HIP, std::string("mpsk_tsplit: ") + (err.empty() ? hipGetErrorString(e) : err.c_str()));
     const int k = *kept;
     REQUIRE(ldc >= k && ldar >= k, "leading dimension of C / AR smaller than the kept rank");
