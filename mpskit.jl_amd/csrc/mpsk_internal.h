@@ -115,7 +115,7 @@ hipError_t copy_strided(const double* src, int64_t srs, int64_t scs, double* dst
 // ---- vector kernels ---------------------------------------------------------------------------
 // xs: HOST array of k device pointers; d_out / d_coefs: device [k]; d_partial: device scratch
 // [MPSK_DOT_SCRATCH doubles].  Vectors must be 16-B aligned.
-constexpr int MPSK_DOT_SCRATCH = 8 * 1024;
+constexpr int MPSK_DOT_SCRATCH = 32 * 1024;     // up to 32 dots x DOT_BLOCKS partial sums (the long fused Gram-Schmidt passes)
 hipError_t vec_multidot(const double* const* xs, int k, const double* y, int64_t n, double* d_out,
                         double* d_partial, hipStream_t s);
 hipError_t vec_axpby(double a, const double* x, double b, double* y, int64_t n, hipStream_t s);

@@ -326,14 +326,88 @@ static void launch_axpy_dot(int nv, int nb, const PtrPack& pk, const double* cf,
   }
 }
 
+// ---- long bases (MD < k <= ML: the restarted solvers at krylovdim 30) ------------------------------------------------
+// The same two fused passes.  The first has to keep an element's k operand values in registers until the element's final
+// y is known (the dots of pass two use both), so it works on single doubles (k + 2k accumulators / coefficients <= 192
+// VGPRs at 32 vectors) in three sizes, padded with zero coefficients on xs[0] (re-reads of a line already in L1); the
+// second needs no retention and loops over k at run time.  Vector passes per CGS2 step: 3k + 5 + k/8 instead of the
+// 4k + 6 k/8 + 1 of the chunked fallback (k = 24: 80 against 115; the step is HBM-bound).
+constexpr int ML = 32;
+struct PtrPackL { const double* p[ML]; };
+
+template <int NVEC>
+__global__ __launch_bounds__(256) void multiaxpy_dot_long_kernel(PtrPackL xs, const double* __restrict__ coefs, double sign,
+                                                                 double* __restrict__ y, int64_t n, int k,
+                                                                 double* __restrict__ partial) {
+  __shared__ double sh[4 * NVEC];
+  double c[NVEC], acc[NVEC];
+#pragma unroll
+  for (int j = 0; j < NVEC; ++j) { c[j] = j < k ? sign * coefs[j] : 0.0; acc[j] = 0.0; }
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    double yv = y[e];
+    double xv[NVEC];
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+      xv[j] = xs.p[j][e];
+      yv += c[j] * xv[j];
+    }
+    y[e] = yv;
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) acc[j] += xv[j] * yv;
+  }
+  block_sum<NVEC>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j)
+      if (j < k) partial[(int64_t)j * DOT_BLOCKS + blockIdx.x] = acc[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void multiaxpy_norm_long_kernel(PtrPackL xs, const double* __restrict__ coefs, double sign,
+                                                                  double* __restrict__ y, int64_t n, int k,
+                                                                  double* __restrict__ partial) {
+  __shared__ double sh[4];
+  __shared__ double cs[ML];
+  if (threadIdx.x < ML) cs[threadIdx.x] = threadIdx.x < k ? sign * coefs[threadIdx.x] : 0.0;
+  __syncthreads();
+  double acc[1] = {0.0};
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    double yv = y[e];
+    for (int j = 0; j < k; ++j) yv += cs[j] * xs.p[j][e];
+    y[e] = yv;
+    acc[0] += yv * yv;
+  }
+  block_sum<1>(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+
+static int dot_grid_long(int64_t n) {          // one double per thread and trip
+  int64_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > DOT_BLOCKS) b = DOT_BLOCKS;
+  return (int)b;
+}
+
 // One CGS2 step of y against xs[0..k) with the remainder's squared norm, d_out = {h1[k], h2[k], |y_final|^2}:
 //   h1 = X^T y ; y -= X h1 (+ h2 = X^T y in the same pass) ; y -= X h2 (+ |y|^2 in the same pass).
-// k <= MD vectors go through the fused kernels; longer bases fall back to the separate passes (a chunked axpy cannot
-// carry dots of the FINAL y).  y is left un-normalised.
+// k <= MD vectors go through the fused kernels, MD < k <= ML through their long twins; beyond that the separate passes (a
+// chunked axpy cannot carry dots of the FINAL y).  y is left un-normalised.
 hipError_t vec_cgs2(const double* const* xs, int k, double* y, int64_t n, double* d_out, double* d_partial, hipStream_t s) {
   if (n <= 0 || k <= 0) return hipErrorInvalidValue;
   hipError_t e = vec_multidot(xs, k, y, n, d_out, d_partial, s);
   if (e != hipSuccess) return e;
+  if (k > MD && k <= ML) {
+    const int nbl = dot_grid_long(n);
+    PtrPackL pk;
+    for (int j = 0; j < ML; ++j) pk.p[j] = xs[j < k ? j : 0];
+    if (k <= 16) hipLaunchKernelGGL(multiaxpy_dot_long_kernel<16>, dim3(nbl), dim3(256), 0, s, pk, d_out, -1.0, y, n, k, d_partial);
+    else if (k <= 24) hipLaunchKernelGGL(multiaxpy_dot_long_kernel<24>, dim3(nbl), dim3(256), 0, s, pk, d_out, -1.0, y, n, k, d_partial);
+    else hipLaunchKernelGGL(multiaxpy_dot_long_kernel<32>, dim3(nbl), dim3(256), 0, s, pk, d_out, -1.0, y, n, k, d_partial);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(k), dim3(256), 0, s, d_partial, nbl, d_out + k);
+    hipLaunchKernelGGL(multiaxpy_norm_long_kernel, dim3(nbl), dim3(256), 0, s, pk, d_out + k, -1.0, y, n, k, d_partial);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, d_partial, nbl, d_out + 2 * k);
+    return hipGetLastError();
+  }
   if (k > MD) {
     if ((e = vec_multiaxpy(xs, d_out, k, -1.0, y, n, s)) != hipSuccess) return e;
     if ((e = vec_multidot(xs, k, y, n, d_out + k, d_partial, s)) != hipSuccess) return e;

@@ -218,6 +218,29 @@ def test_vectors(be):
         assert relerr(be.download(z), 3 * (2 * xs[0] - 0.5 * sum((i + 1) * x for i, x in enumerate(xs)))) < 1e-13
 
 
+@pytest.mark.parametrize("n", [5, 4099, 2 ** 18])
+def test_orth_step_every_basis_length(be, n):
+    """mpsk_vorth_step (CGS2 + normalise, the Krylov loops' orthogonalisation: KrylovKit ModifiedGramSchmidt2) for every
+    basis length 1 .. 34: k <= 8 runs the fused pair of passes, 9 .. 32 their long twins (16 / 24 / 32-vector register
+    variants with zero-padded coefficients), 33+ the chunked fallback -- all against two rounds of classical Gram-Schmidt
+    in numpy on a basis that is only roughly orthonormal (so the second round matters)."""
+    rng = np.random.default_rng(n)
+    for k in range(1, 35):
+        Q, _ = np.linalg.qr(rng.standard_normal((max(n, k), k)))
+        X = (Q[:n] if n >= k else rng.standard_normal((n, k))) + 1e-3 * rng.standard_normal((n, k))
+        y = rng.standard_normal(n)
+        h1 = X.T @ y; y1 = y - X @ h1
+        h2 = X.T @ y1; y2 = y1 - X @ h2
+        dxs = [be.upload(np.ascontiguousarray(X[:, j])) for j in range(k)]
+        dy = be.upload(y)
+        h, beta = be.orth_step(dxs, dy)
+        scale = np.linalg.norm(y)
+        assert np.abs(h - (h1 + h2)).max() < 1e-12 * scale, k
+        assert abs(beta - np.linalg.norm(y2)) < 1e-12 * scale, k
+        if np.linalg.norm(y2) > 1e-8 * scale:
+            assert np.abs(be.download(dy).ravel() - y2 / np.linalg.norm(y2)).max() < 1e-11, k
+
+
 QR_CASES = [(8, 4), (4, 4), (64, 64), (100, 37), (33, 1), (768, 256), (1030, 515), (2048, 1024), (4096, 1024)]
 
 
