@@ -273,6 +273,10 @@ int mpsk_vorth_step(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void
 int mpsk_vorth_step_dev(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, void* y, void* dev_out);
 /* y = sum_j coefs[j] xs[j]   (Ritz vector assembly); asynchronous (host_coefs is copied before the call returns) */
 int mpsk_vlincomb(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, const double* host_coefs, void* y);
+/* ys[j] = sum_i host_coefs[i + k j] xs[i] for j < m, all in ONE pass over the vectors (k + m instead of ~m (k + 6) vector
+ * passes): the basis rotation of KrylovKit's thick restart (shrink step of eigsolve / schursolve at krylovdim 30, which
+ * fixedpoint.jl:19-30 runs with maxiter = 100).  k, m <= 32; outputs must not alias inputs; asynchronous like mpsk_vlincomb. */
+int mpsk_vmultilincomb(mpsk_ctx* ctx, int64_t n, int k, const void* const* xs, int m, void* const* ys, const double* host_coefs);
 /* y = x / |x| (y may be x) and dev_out[0] = |x|^2, both without a host synchronisation: the start / Ritz-vector
  * normalisations of a fixed-budget Krylov solve and the per-site galerkin norms of a sweep are read back once per
  * solve / sweep instead of stalling the stream at every use (normalize! in toolbox.jl:18, fixedpoint.jl:19-30).

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mpsk_vorth_step": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p, c_double_p],
     "mpsk_vorth_step_dev": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, C.c_void_p],
     "mpsk_vlincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, c_double_p, C.c_void_p],
+    "mpsk_vmultilincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_int, c_void_pp, c_double_p],
     "mpsk_vnormalize_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vnrm2_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "mpsk_ctx_qr_retries": [C.c_void_p, C.POINTER(C.c_long)],

@@ -594,6 +594,17 @@ class Backend:
         check(self.lib.mpsk_vlincomb_dev(self.ctx, y.size, len(xs), self._ptrs(xs), coef.ptr, y.ptr), "mpsk_vlincomb_dev")
         return y
 
+    def multilincomb(self, xs, S, outs):
+        """outs[j] = sum_i S[i, j] xs[i] in one pass over the vectors (mpsk_vmultilincomb: the basis rotation of a thick
+        restart); len(xs), len(outs) <= 32, outs disjoint from xs."""
+        S = np.asarray(S, dtype=float)
+        k, m = len(xs), len(outs)
+        assert S.shape == (k, m)
+        cf = (C.c_double * (k * m))(*S.T.reshape(-1))                # column j of S contiguous: coefs[i + k j]
+        check(self.lib.mpsk_vmultilincomb(self.ctx, xs[0].size, k, self._ptrs(xs), m, self._ptrs(outs), cf),
+              "mpsk_vmultilincomb")
+        return outs
+
     def lincomb(self, xs, coefs, out: DTensor = None):
         y = self.empty(xs[0].shape) if out is None else out
         cf = (C.c_double * len(xs))(*[float(c) for c in coefs])

@@ -116,6 +116,7 @@ struct mpsk_hac {
   int pool_idx = -1;
 };
 constexpr int MAXK = 256;
+constexpr int MAXCOEF = 1024;   // coefficient staging: MAXK for mpsk_vlincomb, 32 x 32 for mpsk_vmultilincomb
 
 extern "C" {
 
@@ -137,8 +138,8 @@ int mpsk_ctx_create(int device, mpsk_ctx** out) {
   HIPCHK(hipMalloc(&c->d_scal, sizeof(double) * MAXK));
   HIPCHK(hipMalloc(&c->d_partial, sizeof(double) * MPSK_DOT_SCRATCH));
   HIPCHK(hipHostMalloc(&c->h_scal, sizeof(double) * MAXK, hipHostMallocDefault));
-  HIPCHK(hipMalloc(&c->d_coef, sizeof(double) * MAXK));
-  HIPCHK(hipHostMalloc(&c->h_coef, sizeof(double) * MAXK, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&c->d_coef, sizeof(double) * MAXCOEF));
+  HIPCHK(hipHostMalloc(&c->h_coef, sizeof(double) * MAXCOEF, hipHostMallocDefault));
   HIPCHK(hipEventCreateWithFlags(&c->ev_coef, hipEventDisableTiming | hipEventDisableSystemFence));
   HIPCHK(hipMalloc(&c->d_flag, 64));
   HIPCHK(hipHostMalloc(&c->h_flags, 64, hipHostMallocDefault));
@@ -1906,6 +1907,22 @@ int mpsk_vlincomb(mpsk_ctx* c, int64_t n, int k, const void* const* xs, const do
   c->coef_pending = true;
   HIPCHK(hipMemsetAsync(y, 0, sizeof(double) * n, c->stream));
   HIPCHK(vec_multiaxpy((const double* const*)xs, c->d_coef, k, 1.0, (double*)y, n, c->stream));
+  return MPSK_OK;
+}
+
+// ys[j] = sum_i host_coefs[i + k j] xs[i], j < m: the basis rotation of a thick restart in one pass over the vectors
+int mpsk_vmultilincomb(mpsk_ctx* c, int64_t n, int k, const void* const* xs, int m, void* const* ys, const double* host_coefs) {
+  REQUIRE(c && xs && ys && host_coefs, "NULL argument");
+  REQUIRE(k > 0 && k <= 32 && m > 0 && m <= 32 && n > 0, "needs 0 < k, m <= 32 and n > 0");
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < k; ++i) REQUIRE(ys[j] != xs[i], "outputs must not alias inputs");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->coef_pending) { HIPCHK(hipEventSynchronize(c->ev_coef)); c->coef_pending = false; }
+  std::memcpy(c->h_coef, host_coefs, sizeof(double) * (size_t)k * m);
+  HIPCHK(hipMemcpyAsync(c->d_coef, c->h_coef, sizeof(double) * (size_t)k * m, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->ev_coef, c->stream));
+  c->coef_pending = true;
+  HIPCHK(vec_multilincomb((const double* const*)xs, k, (double* const*)ys, m, c->d_coef, n, c->stream));
   return MPSK_OK;
 }
 

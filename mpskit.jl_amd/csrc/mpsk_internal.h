@@ -127,6 +127,8 @@ hipError_t vec_scal_rsqrt_dev_oop(const double* d_n2, const double* x, double* y
 hipError_t vec_cgs2(const double* const* xs, int k, double* y, int64_t n, double* d_out, double* d_partial, hipStream_t s);
 // Ritz step of a fixed-budget Krylov solve on the device (mpsk_ops.hip: ritz_small_kernel); m <= 32
 hipError_t vec_ritz_small(const double* d_slot, int m, int stride, double* d_coef, double* d_info, hipStream_t s);
+hipError_t vec_multilincomb(const double* const* xs, int k, double* const* ys, int m, const double* d_coefs, int64_t n,
+                            hipStream_t s);   // ys[j] = sum_i d_coefs[i + k j] xs[i]; k, m <= 32
 hipError_t vec_multiaxpy(const double* const* xs, const double* d_coefs, int k, double sign, double* y,
                          int64_t n, hipStream_t s);
 

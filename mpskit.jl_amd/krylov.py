@@ -170,8 +170,11 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         keep = max(1, min(m - 1, (3 * m) // 5))
         if spare is None:
             spare = ws.get(shape, keep, tag="thick-restart")
-        for j in range(keep):
-            be.lincomb(basis[:m], S[:, j], out=spare[j])
+        if hasattr(be, "multilincomb") and m <= 32:
+            be.multilincomb(basis[:m], S[:, :keep], spare[:keep])       # one pass: m + keep vector reads / writes
+        else:
+            for j in range(keep):
+                be.lincomb(basis[:m], S[:, j], out=spare[j])
         resid = basis[m]                                  # v_{m+1}
         coupling = Hm[m, m - 1] * S[m - 1, :keep]
         old = basis[:m]

@@ -218,6 +218,26 @@ def test_vectors(be):
         assert relerr(be.download(z), 3 * (2 * xs[0] - 0.5 * sum((i + 1) * x for i, x in enumerate(xs)))) < 1e-13
 
 
+@pytest.mark.parametrize("k,m", [(1, 1), (3, 2), (8, 5), (9, 9), (16, 10), (17, 3), (30, 18), (32, 32)])
+def test_multilincomb_basis_rotation(be, k, m):
+    """mpsk_vmultilincomb: outs[j] = sum_i S[i, j] xs[i] in one pass (the thick-restart rotation of the Krylov basis,
+    KrylovKit shrink step) == numpy, for every register variant (8 / 16 / 24 / 32 inputs) and odd lengths; aliasing an
+    output with an input is refused."""
+    from mpskit_jl_amd._lib import MpskError
+    rng = np.random.default_rng(10 * k + m)
+    for n in (7, 100003):
+        X = rng.standard_normal((n, k))
+        S = rng.standard_normal((k, m))
+        dxs = [be.upload(np.ascontiguousarray(X[:, i])) for i in range(k)]
+        outs = [be.upload(np.full(n, np.nan)) for _ in range(m)]
+        be.multilincomb(dxs, S, outs)
+        ref = X @ S
+        for j in range(m):
+            assert np.abs(be.download(outs[j]).ravel() - ref[:, j]).max() < 1e-13 * max(1.0, np.abs(ref).max())
+    with pytest.raises(MpskError, match="alias"):
+        be.multilincomb(dxs, S, [dxs[0]] + outs[1:])
+
+
 @pytest.mark.parametrize("n", [5, 4099, 2 ** 18])
 def test_orth_step_every_basis_length(be, n):
     """mpsk_vorth_step (CGS2 + normalise, the Krylov loops' orthogonalisation: KrylovKit ModifiedGramSchmidt2) for every

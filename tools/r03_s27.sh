@@ -4,7 +4,7 @@ set -e
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/s27
 O=gpurun_out/s27
-timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_traces.py -x -q -m gpu -k "orth_step or vectors or vumps or ritz or eigsolve" > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_traces.py tests/test_gpu_algorithms.py -x -q -m gpu -k "orth_step or vectors or vumps or ritz or eigsolve or multilincomb or quasiparticle" > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
 tail -2 $O/pytest.log
 timeout -k 10 300 python tools/bench_configs.py c3 2>&1 | grep "c3 " | tee $O/c3.log
 timeout -k 10 600 python bench.py --no-cpu-baseline --early-sweeps 0 > $O/bench.log 2>&1
