@@ -387,6 +387,34 @@ class Backend:
         check(self.lib.mpsk_qrpos(self.ctx, m, n, A.ptr, m, Q.ptr, m, R.ptr, k), "mpsk_qrpos")
         return Q, R
 
+    def qrpos_c(self, A: DTensor):
+        """QRpos of an interleaved complex128 matrix (upload_c layout: shape (2 m, n) = complex m x n): returns Q (2 m, n) and
+        R (2 n, n), complex upper triangular with a real positive diagonal (mpsk_qrpos under MPSK_C128)."""
+        m2, n = A.shape
+        m = m2 // 2
+        assert m2 == 2 * m and m >= n
+        Q, R = self.empty(m2, n), self.empty(2 * n, n)
+        self._set_dtype(True)
+        try:
+            check(self.lib.mpsk_qrpos(self.ctx, m, n, A.ptr, m, Q.ptr, m, R.ptr, n), "mpsk_qrpos (C128)")
+        finally:
+            self._set_dtype(False)
+        return Q, R
+
+    def lqpos_c(self, A: DTensor):
+        """LQpos of an interleaved complex128 matrix (shape (2 m, n), m <= n): L (2 m, m) lower triangular with a real positive
+        diagonal, Q (2 m, n) with orthonormal rows (mpsk_lqpos under MPSK_C128)."""
+        m2, n = A.shape
+        m = m2 // 2
+        assert m2 == 2 * m and m <= n
+        L, Q = self.empty(m2, m), self.empty(m2, n)
+        self._set_dtype(True)
+        try:
+            check(self.lib.mpsk_lqpos(self.ctx, m, n, A.ptr, m, L.ptr, m, Q.ptr, m), "mpsk_lqpos (C128)")
+        finally:
+            self._set_dtype(False)
+        return L, Q
+
     def qrpos2(self, A1: DTensor, A2: DTensor):
         """two QRpos of equal shape in flight together (two streams inside the ctx)."""
         m, n = A1.shape

@@ -84,6 +84,8 @@ struct mpsk_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;          // transposed operands of mpsk_qrlq_pair
   size_t ws3_bytes = 0;
+  void* cxws[2] = {nullptr, nullptr};     // scratch of the complex128 gauge steps (embedded operands; conjugate transposes)
+  size_t cxws_bytes[2] = {0, 0};
   int* h_flags = nullptr;       // pinned [2]
   // deferred completion of a CholeskyQR gauge step (mpsk_ctx_qr_defer / mpsk_qr_commit): the launches are enqueued, the
   // success flag is read (and a fallback run) only at commit -- the caller fills the gap with work that does not need c->ws
@@ -181,6 +183,7 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->ws2) (void)hipFree(c->ws2);
   if (c->ws3) (void)hipFree(c->ws3);
+  for (int i = 0; i < 2; ++i) if (c->cxws[i]) (void)hipFree(c->cxws[i]);
   for (int i = 1; i < 3; ++i)
     if (c->xstreams[i]) { (void)hipStreamSynchronize(c->xstreams[i]); gemm_release_stream(c->xstreams[i]); (void)hipStreamDestroy(c->xstreams[i]); }
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -1083,7 +1086,11 @@ int mpsk_ctx_qr_retries(mpsk_ctx* c, long* n_retry) {
   return MPSK_OK;
 }
 
-int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
+static int qrpos_c128(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr);
+static int lqpos_c128(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq);
+static int lqpos_f64(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq);
+
+static int qrpos_f64(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
   REQUIRE(c && A && Q && R, "NULL argument");
   REQUIRE(m >= n && n > 0, "needs m >= n > 0");
   REQUIRE(lda >= m && ldq >= m && ldr >= n, "leading dimension too small");
@@ -1091,6 +1098,124 @@ int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int l
   c->defer_next = false;                       // (single factorizations complete at once)
   if (int rc = ensure_ws(c, sizeof(double) * qr_ws_doubles(m, n))) return rc;
   return qrpos_dispatch(c, m, n, (const double*)A, lda, (double*)Q, ldq, (double*)R, ldr, (double*)c->ws);
+}
+// the ABI entry: fp64, or complex128 when the ctx dtype says so (mpsk_ctx_set_dtype; interleaved complex operands)
+int mpsk_qrpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
+  REQUIRE(c, "ctx is NULL");
+  return c->dtype == MPSK_C128 ? qrpos_c128(c, m, n, A, lda, Q, ldq, R, ldr) : qrpos_f64(c, m, n, A, lda, Q, ldq, R, ldr);
+}
+
+// ---- complex128 gauge steps (ctx dtype MPSK_C128) ---------------------------------------------------------------------
+// Operands are interleaved complex128 in column-major order (Julia Array{ComplexF64}): a complex m x n matrix is a real
+// 2m x n matrix H whose row pairs hold (re, im); leading dimensions count COMPLEX elements.  The factorization runs on the
+// real 2m x 2n embedding E = [h_0 | J h_0 | h_1 | J h_1 ...] (J (re, im) = (-im, re)): the real QRpos of an embedding is the
+// embedding of the complex QRpos (R_E upper triangular with a positive diagonal, and the factorization is unique), so the
+// whole CholeskyQR3 / fallback ladder is reused; the price is 2x the flops of a native complex kernel in the GEMM parts and a
+// Cholesky chain of 2n instead of n columns.  Numerically the columns of Q_E along weakly determined directions are not
+// embeddings (perturbed CholeskyQR, Householder completion of rank-deficient input); then Q := the structured part of Q_E,
+// re-orthonormalised by a factorization that is now well conditioned, and R = triu(Q^H A) -- backward stable because those
+// directions carry weight sigma_j (cplx.py: qrpos_structured, the same remedy on the host side).
+__global__ __launch_bounds__(256) void cx_embed_kernel(const double* __restrict__ H, int64_t ldh, int m, int n,
+                                                       double* __restrict__ E, int64_t lde) {
+  const int64_t tot = (int64_t)m * n;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(t % m), b = (int)(t / m);
+    const double re = H[2 * a + ldh * b], im = H[2 * a + 1 + ldh * b];
+    double* e0 = E + 2 * a + lde * (2 * (int64_t)b);
+    double* e1 = e0 + lde;
+    e0[0] = re; e0[1] = im; e1[0] = -im; e1[1] = re;
+  }
+}
+// H = structured part of the (nearly) embedded E: re = (E00 + E11) / 2, im = (E10 - E01) / 2; D (optional) = E - embed(H);
+// upper != 0: complex entries below the diagonal are zeroed and the diagonal is made real (triangular factors)
+__global__ __launch_bounds__(256) void cx_half_kernel(const double* __restrict__ E, int64_t lde, int m, int n,
+                                                      double* __restrict__ H, int64_t ldh, double* __restrict__ D, int64_t ldd,
+                                                      int upper) {
+  const int64_t tot = (int64_t)m * n;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(t % m), b = (int)(t / m);
+    const double* e0 = E + 2 * a + lde * (2 * (int64_t)b);
+    const double* e1 = e0 + lde;
+    double re = 0.5 * (e0[0] + e1[1]), im = 0.5 * (e0[1] - e1[0]);
+    if (upper) { if (a > b) re = im = 0.0; else if (a == b) im = 0.0; }
+    H[2 * a + ldh * b] = re; H[2 * a + 1 + ldh * b] = im;
+    if (D) {
+      double* d0 = D + 2 * a + ldd * (2 * (int64_t)b);
+      double* d1 = d0 + ldd;
+      d0[0] = e0[0] - re; d0[1] = e0[1] - im; d1[0] = e1[0] + im; d1[1] = e1[1] - re;
+    }
+  }
+}
+// out (n x m complex) = conjugate transpose of in (m x n complex)
+__global__ __launch_bounds__(256) void cx_ctranspose_kernel(const double* __restrict__ in, int64_t ldi, int m, int n,
+                                                            double* __restrict__ out, int64_t ldo) {
+  const int64_t tot = (int64_t)m * n;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t % m), j = (int)(t / m);
+    out[2 * j + ldo * i] = in[2 * i + ldi * j];
+    out[2 * j + 1 + ldo * i] = -in[2 * i + 1 + ldi * j];
+  }
+}
+static int cx_scratch(mpsk_ctx* c, int which, size_t bytes, double** out) {
+  if (c->cxws_bytes[which] < bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->cxws[which]) HIPCHK(hipFree(c->cxws[which]));
+    c->cxws[which] = nullptr; c->cxws_bytes[which] = 0;
+    if (hipMalloc(&c->cxws[which], bytes) != hipSuccess) return fail(MPSK_ERR_NOMEM, "complex gauge step: workspace hipMalloc failed");
+    c->cxws_bytes[which] = bytes;
+  }
+  *out = (double*)c->cxws[which];
+  return MPSK_OK;
+}
+static int qrpos_c128(mpsk_ctx* c, int m, int n, const void* A, int lda, void* Q, int ldq, void* R, int ldr) {
+  REQUIRE(c && A && Q && R, "NULL argument");
+  REQUIRE(m >= n && n > 0, "needs m >= n > 0");
+  REQUIRE(lda >= m && ldq >= m && ldr >= n, "leading dimension too small");
+  HIPCHK(hipSetDevice(c->device));
+  const int m2 = 2 * m, n2 = 2 * n;
+  const size_t en = (size_t)m2 * n2, rn = (size_t)n2 * n2;
+  double* buf = nullptr;
+  if (int rc = cx_scratch(c, 0, sizeof(double) * (3 * en + rn), &buf)) return rc;
+  double *E = buf, *QE = E + en, *E2 = QE + en, *RE = E2 + en;
+  const int grid = 1024;
+  hipLaunchKernelGGL(cx_embed_kernel, dim3(grid), dim3(256), 0, c->stream, (const double*)A, (int64_t)2 * lda, m, n, E, (int64_t)m2);
+  if (int rc = qrpos_f64(c, m2, n2, E, m2, QE, m2, RE, n2)) return rc;
+  hipLaunchKernelGGL(cx_half_kernel, dim3(grid), dim3(256), 0, c->stream, QE, (int64_t)m2, m, n, (double*)Q, (int64_t)2 * ldq, E2,
+                     (int64_t)m2, 0);
+  double defect = 0.0;
+  if (int rc = mpsk_vnrm2(c, (int64_t)en, E2, &defect)) return rc;
+  if (defect <= 1.0e-13 * std::sqrt((double)n2)) {
+    hipLaunchKernelGGL(cx_half_kernel, dim3(grid), dim3(256), 0, c->stream, RE, (int64_t)n2, n, n, (double*)R, (int64_t)2 * ldr,
+                       (double*)nullptr, (int64_t)0, 1);
+    return MPSK_OK;
+  }
+  // structured part -> re-orthonormalise (well conditioned: structure preserving to rounding) -> R = triu(Q^H A)
+  hipLaunchKernelGGL(cx_embed_kernel, dim3(grid), dim3(256), 0, c->stream, (const double*)Q, (int64_t)2 * ldq, m, n, E2, (int64_t)m2);
+  if (int rc = qrpos_f64(c, m2, n2, E2, m2, QE, m2, RE, n2)) return rc;
+  hipLaunchKernelGGL(cx_half_kernel, dim3(grid), dim3(256), 0, c->stream, QE, (int64_t)m2, m, n, (double*)Q, (int64_t)2 * ldq,
+                     (double*)nullptr, (int64_t)0, 0);
+  hipLaunchKernelGGL(cx_embed_kernel, dim3(grid), dim3(256), 0, c->stream, (const double*)Q, (int64_t)2 * ldq, m, n, QE, (int64_t)m2);
+  GemmArgs g = mk(QE, E, RE, n2, n2, m2, m2, m2, n2, 1, 0);
+  HIPCHK(gemm_f64(g, c->stream));
+  hipLaunchKernelGGL(cx_half_kernel, dim3(grid), dim3(256), 0, c->stream, RE, (int64_t)n2, n, n, (double*)R, (int64_t)2 * ldr,
+                     (double*)nullptr, (int64_t)0, 1);
+  return MPSK_OK;
+}
+// A (m x n complex, m <= n) = L Q: the QRpos of A^H, conjugate-transposed back
+static int lqpos_c128(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq) {
+  REQUIRE(c && A && Q && L, "NULL argument");
+  REQUIRE(m <= n && m > 0, "needs 0 < m <= n");
+  REQUIRE(lda >= m && ldq >= m && ldl >= m, "leading dimension too small");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t an = (size_t)2 * n * m, ln = (size_t)2 * m * m;
+  double* buf = nullptr;
+  if (int rc = cx_scratch(c, 1, sizeof(double) * (2 * an + ln), &buf)) return rc;
+  double *At = buf, *Qt = At + an, *Rt = Qt + an;
+  hipLaunchKernelGGL(cx_ctranspose_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)A, (int64_t)2 * lda, m, n, At, (int64_t)2 * n);
+  if (int rc = qrpos_c128(c, n, m, At, n, Qt, n, Rt, m)) return rc;
+  hipLaunchKernelGGL(cx_ctranspose_kernel, dim3(1024), dim3(256), 0, c->stream, Qt, (int64_t)2 * n, n, m, (double*)Q, (int64_t)2 * ldq);
+  hipLaunchKernelGGL(cx_ctranspose_kernel, dim3(1024), dim3(256), 0, c->stream, Rt, (int64_t)2 * m, m, m, (double*)L, (int64_t)2 * ldl);
+  return MPSK_OK;
 }
 
 // completion of ONE CholeskyQR3 factorization whose launches are already on `s`: wait, read the device flag, repeat the
@@ -1312,6 +1437,10 @@ int mpsk_qrlq_pair(mpsk_ctx* c, int m, int n, const void* A1, int lda1, void* Q1
 
 // LQ of A (m x n, m <= n) through the QR of A^T:  A^T = Qt Rt  ->  L = Rt^T, Q = Qt^T
 int mpsk_lqpos(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq) {
+  REQUIRE(c, "ctx is NULL");
+  return c->dtype == MPSK_C128 ? lqpos_c128(c, m, n, A, lda, L, ldl, Q, ldq) : lqpos_f64(c, m, n, A, lda, L, ldl, Q, ldq);
+}
+static int lqpos_f64(mpsk_ctx* c, int m, int n, const void* A, int lda, void* L, int ldl, void* Q, int ldq) {
   REQUIRE(c && A && Q && L, "NULL argument");
   REQUIRE(m <= n && m > 0, "needs 0 < m <= n");
   REQUIRE(lda >= m && ldq >= m && ldl >= m, "leading dimension too small");
@@ -1625,7 +1754,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
         // theta (m x n): Y_k = right singular vectors.  B = theta Y_k = U_k S_k ; AL C = QRpos(B) ; AR = Y_k^T
         GemmArgs g = mk((const double*)theta, Y, T, m, k, n, ldt, nn, m);
         HIPCHK(gemm_f64(g, c->stream));
-        if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
+        if (int rc = qrpos_f64(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
         HIPCHK(transpose(Y, nn, n, k, (double*)AR, ldar, c->stream));
       } else {
         // theta (m x n), m < n: Y_k = left singular vectors = AL.  M = Y_k^T theta = S_k V_k^T ; C AR = LQpos(M)
@@ -1633,7 +1762,7 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
                                 hipMemcpyDeviceToDevice, c->stream));
         GemmArgs g = mk(Y, (const double*)theta, T, k, n, m, nn, ldt, k, 1, 0);
         HIPCHK(gemm_f64(g, c->stream));
-        if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
+        if (int rc = lqpos_f64(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
       }
       return MPSK_OK;
     }
@@ -1772,9 +1901,9 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
     }
     SPLIT_STAGE("before LQpos / QRpos");
     if (!transposed) {
-      if (int rc = mpsk_lqpos(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
+      if (int rc = lqpos_f64(c, k, n, T, k, Cm, ldc, AR, ldar)) return rc;
     } else {
-      if (int rc = mpsk_qrpos(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
+      if (int rc = qrpos_f64(c, m, k, T, m, AL, ldal, Cm, ldc)) return rc;
       HIPCHK(transpose(Vk, n, n, k, (double*)AR, ldar, c->stream));
     }
     SPLIT_STAGE("done");

@@ -225,3 +225,41 @@ def test_structured_split_through_the_truncation_aware_tsplit(be, m, n, k):
         best_err = np.linalg.norm(sv[k:])
         assert abs(np.linalg.norm(th - rec) - best_err) < 1e-11
         assert abs(disc - best_err) < 1e-11
+
+
+@pytest.mark.parametrize("m,n", [(5, 3), (64, 64), (200, 130), (1024, 512)])
+def test_qrpos_lqpos_complex128_through_the_abi(be, m, n):
+    """mpsk_qrpos / mpsk_lqpos under MPSK_C128 (interleaved complex operands; orthoview.jl:49-60 on ComplexF64 tensors)
+    against the oracle's complex QRpos / LQpos: Q^H Q = I, R upper triangular with a REAL positive diagonal, A = Q R, and
+    Q, R equal to the oracle's (the factorization is unique) to 1e-12; the same for a 1e-10-conditioned matrix and an
+    exactly rank-deficient one (factors compared through A = Q R and the isometry only: the completion is arbitrary)."""
+    rng = np.random.default_rng(m * n)
+    for kind in ("random", "graded", "rankdef"):
+        A = rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))
+        if kind == "graded":
+            U, _ = np.linalg.qr(A)
+            V, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+            A = (U * np.logspace(0, -10, n)) @ V.conj().T
+        elif kind == "rankdef" and n >= 3:
+            A[:, n - 1] = A[:, 0] * (0.3 - 0.2j) + A[:, 1]
+        Q, R = be.qrpos_c(be.upload_c(A))
+        Q, R = be.download_c(Q), be.download_c(R)
+        assert Q.shape == (m, n) and R.shape == (n, n)
+        assert np.abs(Q.conj().T @ Q - np.eye(n)).max() < 1e-12
+        assert np.abs(np.tril(R, -1)).max() == 0.0 and np.abs(np.diag(R).imag).max() == 0.0
+        assert np.all(np.diag(R).real >= -1e-13 * np.abs(R).max())          # (a vanishing pivot of rank-deficient input: 0 to rounding)
+        assert np.abs(Q @ R - A).max() < 1e-12 * np.abs(A).max() * n
+        if kind == "random":
+            Qo, Ro = mo.qrpos(A)
+            assert np.abs(Q - Qo).max() < 1e-12 and np.abs(R - Ro).max() < 1e-12 * np.abs(Ro).max()
+        # LQpos of the conjugate transpose problem (n x m, wide)
+        B = A.conj().T.copy()
+        L, Ql = be.lqpos_c(be.upload_c(B))
+        L, Ql = be.download_c(L), be.download_c(Ql)
+        assert L.shape == (n, n) and Ql.shape == (n, m)
+        assert np.abs(Ql @ Ql.conj().T - np.eye(n)).max() < 1e-12
+        assert np.abs(np.triu(L, 1)).max() == 0.0 and np.abs(np.diag(L).imag).max() == 0.0
+        assert np.abs(L @ Ql - B).max() < 1e-12 * np.abs(B).max() * n
+        if kind == "random":
+            Lo, Qlo = mo.lqpos(B)
+            assert np.abs(L - Lo).max() < 1e-12 * np.abs(Lo).max() and np.abs(Ql - Qlo).max() < 1e-12
