@@ -36,17 +36,20 @@
  *    INTERLEAVED complex128 in the same column-major index order (TensorKit / Julia Array{ComplexF64} storage); a
  *    complex MPO slice takes interleaved scalars[2 odim^2] and dense blocks.  Internally a complex product runs on
  *    the real fp64 MFMA core as two K-segments (re / im of the second operand, the first one through a loader that
- *    multiplies by i): 4x the real flops, the complex optimum.  The single gauge steps mpsk_qrpos / mpsk_lqpos follow
- *    mpsk_ctx_set_dtype too: with MPSK_C128 their operands are interleaved complex matrices (leading dimensions count
+ *    multiplies by i): 4x the real flops, the complex optimum.  The single gauge steps mpsk_qrpos / mpsk_lqpos and the
+ *    two-site split mpsk_tsplit follow mpsk_ctx_set_dtype too: with MPSK_C128 their operands are interleaved complex matrices (leading dimensions count
  *    COMPLEX elements), Q / R / L come back complex with a real positive diagonal on the triangular factor
  *    (TensorKit leftorth! / rightorth! with QRpos() / LQpos() on ComplexF64 tensors).  They run on the real 2m x 2n
  *    embedding INSIDE the library -- 2x the GEMM flops of a native complex kernel and a Cholesky chain of 2n columns --
  *    and keep the complex structure also for ill-conditioned / rank-deficient input (structured part + one more
- *    factorization, R = triu(Q^H A)); the caller's tensors stay interleaved (2x the real memory, not 4x).  The remaining
- *    entry points (mpsk_qrpos2, mpsk_qrlq_pair, mpsk_tsvd, mpsk_tsplit, Krylov vector helpers, mpsk_gemm,
- *    mpsk_regularize) are fp64 only and ignore the ctx dtype: a complex host runs its vector arithmetic on the 2n doubles
- *    of an interleaved vector (real inner products suffice for the Hermitian Lanczos solvers) and its two-site split
- *    through the real embedding (mpskit.jl_amd/cplx.py: split_two_site).
+ *    factorization, R = triu(Q^H A)); the caller's tensors stay interleaved (2x the real memory, not 4x).  Complex
+ *    mpsk_tsplit (max_keep only: trunc_err must be 0) returns complex isometries AL / AR, C lower triangular with a real
+ *    positive diagonal and the kept COMPLEX singular values; the real split of the embedding (every value twice, arbitrary
+ *    basis inside each pair) only supplies the kept subspace, which is made an embedding again by projecting structured
+ *    random vectors on it, with a J-invariant choice inside a cluster that straddles the cut.  The remaining entry points
+ *    (mpsk_qrpos2, mpsk_qrlq_pair, mpsk_tsvd, Krylov vector helpers, mpsk_gemm, mpsk_regularize) are fp64 only and ignore
+ *    the ctx dtype: a complex host runs its vector arithmetic on the 2n doubles of an interleaved vector (real inner
+ *    products suffice for the Hermitian Lanczos solvers).
  */
 #ifndef MPSK_H
 #define MPSK_H

@@ -415,6 +415,26 @@ class Backend:
             self._set_dtype(False)
         return L, Q
 
+    def tsplit_c(self, theta: DTensor, max_keep=0):
+        """Two-site split of an interleaved complex128 tensor (shape (2 m, n) = complex m x n; mpsk_tsplit under MPSK_C128,
+        truncdim scheme): al (2 m, k), c (2 k, k) lower triangular, ar (2 k, n), the k kept singular values, discarded norm."""
+        m2, n = theta.shape
+        m = m2 // 2
+        kf = min(m, n)
+        AL, Cm, AR, S = self.empty(m2, kf), self.empty(2 * kf, kf), self.empty(2 * kf, n), self.empty(kf)
+        kept, disc = C.c_int(0), C.c_double(0.0)
+        self._set_dtype(True)
+        try:
+            check(self.lib.mpsk_tsplit(self.ctx, m, n, theta.ptr, m, int(max_keep), 0.0, AL.ptr, m, Cm.ptr, kf, AR.ptr, kf,
+                                       S.ptr, C.byref(kept), C.byref(disc)), "mpsk_tsplit (C128)")
+        finally:
+            self._set_dtype(False)
+        k = kept.value
+        c, ar = self.empty(2 * k, k), self.empty(2 * k, n)
+        self.copy2d(2 * k, k, Cm.ptr, 2 * kf, c.ptr, 2 * k)
+        self.copy2d(2 * k, n, AR.ptr, 2 * kf, ar.ptr, 2 * k)
+        return DTensor(AL.buf, (m2, k)), c, ar, self.download(DTensor(S.buf, (k,))), disc.value
+
     def qrpos2(self, A1: DTensor, A2: DTensor):
         """two QRpos of equal shape in flight together (two streams inside the ctx)."""
         m, n = A1.shape

@@ -84,8 +84,8 @@ struct mpsk_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;          // transposed operands of mpsk_qrlq_pair
   size_t ws3_bytes = 0;
-  void* cxws[2] = {nullptr, nullptr};     // scratch of the complex128 gauge steps (embedded operands; conjugate transposes)
-  size_t cxws_bytes[2] = {0, 0};
+  void* cxws[3] = {nullptr, nullptr, nullptr};     // scratch of the complex128 gauge steps (embedded operands; conjugate transposes; split)
+  size_t cxws_bytes[3] = {0, 0, 0};
   int* h_flags = nullptr;       // pinned [2]
   // deferred completion of a CholeskyQR gauge step (mpsk_ctx_qr_defer / mpsk_qr_commit): the launches are enqueued, the
   // success flag is read (and a fallback run) only at commit -- the caller fills the gap with work that does not need c->ws
@@ -183,7 +183,7 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->ws2) (void)hipFree(c->ws2);
   if (c->ws3) (void)hipFree(c->ws3);
-  for (int i = 0; i < 2; ++i) if (c->cxws[i]) (void)hipFree(c->cxws[i]);
+  for (int i = 0; i < 3; ++i) if (c->cxws[i]) (void)hipFree(c->cxws[i]);
   for (int i = 1; i < 3; ++i)
     if (c->xstreams[i]) { (void)hipStreamSynchronize(c->xstreams[i]); gemm_release_stream(c->xstreams[i]); (void)hipStreamDestroy(c->xstreams[i]); }
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -1612,8 +1612,8 @@ static int split_iterate(mpsk_ctx* c, int mm, int nn, const double* Ap, int lda,
   return MPSK_OK;
 }
 
-int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
-                void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
+static int tsplit_f64(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
+                      void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
   REQUIRE(c && theta && AL && Cm && AR && S && kept && disc_norm, "NULL argument");
   REQUIRE(m > 0 && n > 0, "dimensions must be positive");
   const int mm = m < n ? n : m, nn = m < n ? m : n, transposed = m < n ? 1 : 0;
@@ -1911,6 +1911,106 @@ int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_k
   }
   return fail(MPSK_ERR_HIP, "mpsk_tsplit: internal error (no path finished)");
 #undef SPLIT_STAGE
+}
+
+// ---- complex128 two-site split (ctx dtype MPSK_C128) -------------------------------------------------------------------
+// theta (m x n complex, interleaved) ~ AL (m x k) C (k x k) AR (k x n), all complex, AL / AR isometries, C lower triangular
+// with a real positive diagonal, S the k kept COMPLEX singular values.  Runs on the real embedding E (2m x 2n), whose
+// singular values are those of theta, each twice: the real split of E returns an arbitrary basis inside every doubled
+// value, so what is taken from it is the kept SUBSPACE (2k + 16 leading left vectors through the truncation-aware
+// real split), made an embedding again by projecting structured random vectors on it -- the construction of
+// cplx.split_two_site (mpskit.jl_amd/cplx.py), including a J-invariant choice inside a cluster that straddles the cut.
+// Truncation by max_keep only (truncdim); trunc_err > 0 is refused.
+static int tsplit_c128(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
+                       void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
+  REQUIRE(c && theta && AL && Cm && AR && S && kept && disc_norm, "NULL argument");
+  REQUIRE(m > 0 && n > 0, "dimensions must be positive");
+  REQUIRE(trunc_err == 0.0, "complex mpsk_tsplit truncates by max_keep only (trunc_err must be 0)");
+  const int kfull = m < n ? m : n;
+  REQUIRE(2 * kfull > 64, "mpsk_tsplit needs 2 min(m, n) > 64 for complex tensors");
+  const int k = (max_keep > 0 && max_keep < kfull) ? max_keep : kfull;
+  REQUIRE(ldt >= m && ldal >= m && ldc >= k && ldar >= k, "leading dimension too small");
+  HIPCHK(hipSetDevice(c->device));
+  const int m2 = 2 * m, n2 = 2 * n, kE = 2 * kfull, K2 = 2 * k;
+  const auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  const size_t e_d = ev((size_t)m2 * n2), al_d = ev((size_t)m2 * kE), c_d = ev((size_t)kE * kE), ar_d = ev((size_t)kE * n2);
+  const size_t b_d = ev((size_t)m2 * K2), x_d = ev((size_t)m2 * K2), g_d = ev((size_t)kE * K2), me_d = ev((size_t)K2 * n2);
+  const size_t mh_d = ev((size_t)2 * k * n), r_d = ev((size_t)K2 * K2);
+  double* buf = nullptr;
+  if (int rc = cx_scratch(c, 2, sizeof(double) * (e_d + al_d + c_d + ar_d + ev((size_t)kE) + 2 * b_d + 2 * x_d + g_d + me_d + mh_d + r_d), &buf))
+    return rc;
+  double *E = buf, *ALe = E + e_d, *Ce = ALe + al_d, *ARe = Ce + c_d, *Se = ARe + ar_d, *B = Se + ev((size_t)kE), *W = B + b_d;
+  double *Xh = W + b_d, *Xe = Xh + x_d, *G = Xe + x_d, *Me = G + g_d, *Mh = Me + me_d, *Rs = Mh + mh_d;
+  hipLaunchKernelGGL(cx_embed_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)theta, (int64_t)2 * ldt, m, n, E, (int64_t)m2);
+  std::vector<double> hs;
+  int lo = K2, hi = K2, have = 0;
+  for (int pad = 16;; pad *= 4) {
+    int req = K2 + pad;
+    if (req > kE) req = kE;
+    int kk = 0;
+    double dn = 0.0;
+    if (int rc = tsplit_f64(c, m2, n2, E, m2, req, 0.0, ALe, m2, Ce, kE, ARe, kE, Se, &kk, &dn)) return rc;
+    have = kk;
+    hs.resize(have);
+    HIPCHK(hipMemcpyAsync(hs.data(), Se, sizeof(double) * have, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // [lo, hi): the even-aligned run of singular values equal to hs[K2 - 1] to 1e-8 -- the cluster the cut may split
+    const double sk = hs[K2 - 1], tolc = 1.0e-8 * sk + 1.0e-14 * hs[0];
+    lo = K2; while (lo > 0 && std::fabs(hs[lo - 1] - sk) <= tolc) --lo;
+    hi = K2; while (hi < have && std::fabs(hs[hi] - sk) <= tolc) ++hi;
+    lo -= lo & 1; hi += hi & 1;
+    if (hi > have) hi = have;
+    if (hi < have || have >= kE || pad > 4096) break;     // the cluster ends inside what was computed (or nothing is left)
+  }
+  // B: orthonormal basis of the kept, J-invariant subspace
+  if (hi == K2) {
+    HIPCHK(hipMemcpy2DAsync(B, sizeof(double) * m2, ALe, sizeof(double) * m2, sizeof(double) * m2, K2, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    if (lo > 0) HIPCHK(hipMemcpy2DAsync(B, sizeof(double) * m2, ALe, sizeof(double) * m2, sizeof(double) * m2, lo, hipMemcpyDeviceToDevice, c->stream));
+    const int r2 = K2 - lo, nc = hi - lo;
+    const double* Uc = ALe + (size_t)m2 * lo;
+    hipLaunchKernelGGL(split_fill_kernel, dim3(1024), dim3(256), 0, c->stream, Xh, (int64_t)m2 * (r2 / 2), 0xc1u);
+    hipLaunchKernelGGL(cx_embed_kernel, dim3(1024), dim3(256), 0, c->stream, Xh, (int64_t)m2, m, r2 / 2, Xe, (int64_t)m2);
+    GemmArgs g1 = mk(Uc, Xe, G, nc, r2, m2, m2, m2, nc, 1, 0);            // Uc^T Xc
+    HIPCHK(gemm_f64(g1, c->stream));
+    GemmArgs g2 = mk(Uc, G, W, m2, r2, nc, m2, nc, m2);                   // Uc (Uc^T Xc)
+    HIPCHK(gemm_f64(g2, c->stream));
+    if (int rc = qrpos_f64(c, m2, r2, W, m2, B + (size_t)m2 * lo, m2, Rs, r2)) return rc;
+  }
+  // embedded orthonormal basis of that subspace: structured random vectors projected on it, QRpos
+  hipLaunchKernelGGL(split_fill_kernel, dim3(1024), dim3(256), 0, c->stream, Xh, (int64_t)m2 * k, 0xc2u);
+  hipLaunchKernelGGL(cx_embed_kernel, dim3(1024), dim3(256), 0, c->stream, Xh, (int64_t)m2, m, k, Xe, (int64_t)m2);
+  GemmArgs g3 = mk(B, Xe, G, K2, K2, m2, m2, m2, K2, 1, 0);
+  HIPCHK(gemm_f64(g3, c->stream));
+  GemmArgs g4 = mk(B, G, W, m2, K2, K2, m2, K2, m2);
+  HIPCHK(gemm_f64(g4, c->stream));
+  if (int rc = qrpos_f64(c, m2, K2, W, m2, B, m2, Rs, K2)) return rc;          // B <- al_E (embedded, m2 x K2)
+  hipLaunchKernelGGL(cx_half_kernel, dim3(1024), dim3(256), 0, c->stream, B, (int64_t)m2, m, k, (double*)AL, (int64_t)2 * ldal,
+                     (double*)nullptr, (int64_t)0, 0);
+  // M = AL^H theta (k x n complex) through the embedded product, then C AR = LQpos(M)
+  GemmArgs g5 = mk(B, E, Me, K2, n2, m2, m2, m2, K2, 1, 0);
+  HIPCHK(gemm_f64(g5, c->stream));
+  hipLaunchKernelGGL(cx_half_kernel, dim3(1024), dim3(256), 0, c->stream, Me, (int64_t)K2, k, n, Mh, (int64_t)2 * k,
+                     (double*)nullptr, (int64_t)0, 0);
+  double tn = 0.0, mn = 0.0;
+  if (int rc = mpsk_vnrm2(c, (int64_t)m2 * n2, E, &tn)) return rc;           // |E|^2 = 2 |theta|^2
+  if (int rc = mpsk_vnrm2(c, (int64_t)2 * k * n, Mh, &mn)) return rc;
+  if (int rc = lqpos_c128(c, k, n, Mh, k, Cm, ldc, AR, ldar)) return rc;
+  std::vector<double> sc(kfull, std::nan(""));
+  for (int j = 0; j < k; ++j) sc[j] = hs[2 * j];
+  HIPCHK(hipMemcpyAsync(S, sc.data(), sizeof(double) * kfull, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));                                    // sc is a host temporary
+  *kept = k;
+  *disc_norm = std::sqrt(std::max(0.5 * tn * tn - mn * mn, 0.0));
+  return MPSK_OK;
+}
+
+// the ABI entry: fp64, or complex128 when the ctx dtype says so (mpsk_ctx_set_dtype)
+int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
+                void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
+  REQUIRE(c, "ctx is NULL");
+  return c->dtype == MPSK_C128 ? tsplit_c128(c, m, n, theta, ldt, max_keep, trunc_err, AL, ldal, Cm, ldc, AR, ldar, S, kept, disc_norm)
+                               : tsplit_f64(c, m, n, theta, ldt, max_keep, trunc_err, AL, ldal, Cm, ldc, AR, ldar, S, kept, disc_norm);
 }
 
 int mpsk_ctx_set_svd_mode(mpsk_ctx* c, int precondition) {

@@ -263,3 +263,31 @@ def test_qrpos_lqpos_complex128_through_the_abi(be, m, n):
         if kind == "random":
             Lo, Qlo = mo.lqpos(B)
             assert np.abs(L - Lo).max() < 1e-12 * np.abs(Lo).max() and np.abs(Ql - Qlo).max() < 1e-12
+
+
+@pytest.mark.parametrize("m,n,k", [(192, 160, 40), (160, 192, 40), (256, 256, 64), (96, 80, 0), (512, 512, 128)])
+def test_tsplit_complex128_through_the_abi(be, m, n, k):
+    """mpsk_tsplit under MPSK_C128 (tsvd!(theta; trunc = truncdim(k)) of a ComplexF64 two-site tensor, dmrg.jl:96-104):
+    al / ar complex isometries, c lower triangular with a real positive diagonal, the kept values are the complex singular
+    values, al c ar is the optimal rank-k truncation (numpy complex SVD) -- also with a degenerate pair of complex values
+    across the cut (a 4-fold cluster of the real embedding the library works on)."""
+    rng = np.random.default_rng(m + n + k)
+    r = min(m, n)
+    kk = k if k > 0 else r
+    for degenerate in (False, True):
+        U, _ = np.linalg.qr(rng.standard_normal((m, r)) + 1j * rng.standard_normal((m, r)))
+        V, _ = np.linalg.qr(rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r)))
+        sv = np.logspace(0, -5, r)
+        if degenerate and kk < r:
+            sv[kk] = sv[kk - 1]
+        th = (U * sv) @ V.conj().T
+        al, c, ar, S, disc = be.tsplit_c(be.upload_c(th), max_keep=k)
+        A, Cm, B = be.download_c(al), be.download_c(c), be.download_c(ar)
+        assert A.shape == (m, kk) and Cm.shape == (kk, kk) and B.shape == (kk, n) and len(S) == kk
+        assert np.abs(A.conj().T @ A - np.eye(kk)).max() < 1e-12 and np.abs(B @ B.conj().T - np.eye(kk)).max() < 1e-12
+        assert np.abs(np.triu(Cm, 1)).max() == 0.0 and np.abs(np.diag(Cm).imag).max() == 0.0
+        assert np.abs(S - sv[:kk]).max() < 1e-12
+        best = np.linalg.norm(sv[kk:])
+        assert abs(np.linalg.norm(th - A @ Cm @ B) - best) < 1e-11
+        assert abs(disc - best) < 1e-7 + 1e-11 * (best > 1e-6)      # (|theta|^2 - |c|^2 cancels for tiny discarded weights)
+        assert np.abs(np.linalg.svd(Cm, compute_uv=False) - sv[:kk]).max() < 1e-12
