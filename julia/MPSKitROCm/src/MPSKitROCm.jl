@@ -197,18 +197,32 @@ function transfer_right(v::ROCTensor{3}, H::ROCSlice, A::ROCTensor{3}, Ab::ROCTe
 end
 
 # ---- gauge steps (TensorKit leftorth!/rightorth!/tsvd! on the matricised tensor) ----
+# mpsk_qrpos / mpsk_lqpos / mpsk_tsplit follow the ctx dtype (include/mpsk.h): under MPSK_C128 their operands are the
+# interleaved bytes of an Array{ComplexF64}, leading dimensions count complex elements
+function with_dtype(f, cplx::Bool)
+    check(ccall((:mpsk_ctx_set_dtype, libmpsk[]), Cint, (Ptr{Cvoid}, Cint), CTX[], cplx ? 1 : 0))
+    try
+        return f()
+    finally
+        cplx && check(ccall((:mpsk_ctx_set_dtype, libmpsk[]), Cint, (Ptr{Cvoid}, Cint), CTX[], 0))
+    end
+end
 function qrpos(A::ROCTensor{2})
     m, n = A.dims
-    Q, R = ROCTensor((m, n)), ROCTensor((n, n))
-    check(ccall((:mpsk_qrpos, libmpsk[]), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-        CTX[], m, n, A.ptr, m, Q.ptr, m, R.ptr, n))
+    Q, R = ROCTensor((m, n); cplx=A.cplx), ROCTensor((n, n); cplx=A.cplx)
+    with_dtype(A.cplx) do
+        check(ccall((:mpsk_qrpos, libmpsk[]), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+            CTX[], m, n, A.ptr, m, Q.ptr, m, R.ptr, n))
+    end
     return Q, R
 end
 function lqpos(A::ROCTensor{2})
     m, n = A.dims
-    L, Q = ROCTensor((m, m)), ROCTensor((m, n))
-    check(ccall((:mpsk_lqpos, libmpsk[]), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-        CTX[], m, n, A.ptr, m, L.ptr, m, Q.ptr, m))
+    L, Q = ROCTensor((m, m); cplx=A.cplx), ROCTensor((m, n); cplx=A.cplx)
+    with_dtype(A.cplx) do
+        check(ccall((:mpsk_lqpos, libmpsk[]), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+            CTX[], m, n, A.ptr, m, L.ptr, m, Q.ptr, m))
+    end
     return L, Q
 end
 function tsvd(theta::ROCTensor{2}; truncdim::Int=0, truncerr::Float64=0.0)
@@ -262,13 +276,18 @@ end
 # c comes back triangular instead of diagonal (al*c*ar is the same truncated theta, al / ar isometries): no rotation
 # accumulation in the Jacobi sweeps.  S is a min(m, n) buffer (include/mpsk.h): the kept Schmidt values lead it; with the
 # truncation-aware default (svd mode 3) only the first r = truncdim + max(64, truncdim / 2) entries are computed, NaN behind.
+# Complex theta (truncdim scheme only): al / ar complex isometries, c lower triangular with a real positive diagonal.
 function tsplit(theta::ROCTensor{2}; truncdim::Int=0, truncerr::Float64=0.0)
     m, n = theta.dims; k = min(m, n); kmax = truncdim > 0 ? min(k, truncdim) : k
-    AL, Cm, AR, S = ROCTensor((m, kmax)), ROCTensor((kmax, kmax)), ROCTensor((kmax, n)), ROCTensor((k,))
+    cx = theta.cplx
+    AL, Cm, AR = ROCTensor((m, kmax); cplx=cx), ROCTensor((kmax, kmax); cplx=cx), ROCTensor((kmax, n); cplx=cx)
+    S = ROCTensor((k,))                                           # singular values are real
     kept = Ref{Cint}(0); disc = Ref{Float64}(0)
-    check(ccall((:mpsk_tsplit, libmpsk[]), Cint,
-        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ref{Cint}, Ref{Float64}),
-        CTX[], m, n, theta.ptr, m, truncdim, truncerr, AL.ptr, m, Cm.ptr, kmax, AR.ptr, kmax, S.ptr, kept, disc))
+    with_dtype(cx) do
+        check(ccall((:mpsk_tsplit, libmpsk[]), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ref{Cint}, Ref{Float64}),
+            CTX[], m, n, theta.ptr, m, truncdim, truncerr, AL.ptr, m, Cm.ptr, kmax, AR.ptr, kmax, S.ptr, kept, disc))
+    end
     return AL, Cm, AR, S, Int(kept[]), disc[]
 end
 
