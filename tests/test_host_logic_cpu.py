@@ -593,3 +593,29 @@ def test_complex_states_in_changebonds_and_finite_excited(cb):
     w = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, Lx))
     assert abs(ens[0] - w[1]) < 1e-7 and sts[0].cplx
     assert abs(float(np.sum(mk.expectation_value(g0, Hg, ge))) - w[0]) < 1e-9
+
+
+def test_structured_split_fast_path_host_logic(cb):
+    """cplx.split_two_site through Backend.tsplit (the 2 k + 16 leading vectors of the truncation-aware split) instead of the
+    full tsvd, on the CPU stand-in: embedded isometries, complex Schmidt values and the optimal truncation, with and without
+    a degenerate pair of complex singular values across the cut; the stand-in counts the calls."""
+    from mpskit_jl_amd import cplx
+    rng = np.random.default_rng(77)
+    m, n, k = 44, 40, 10
+    for degenerate in (False, True):
+        U, _ = np.linalg.qr(rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n)))
+        V, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        sv = np.logspace(0, -4, n)
+        if degenerate:
+            sv[k] = sv[k - 1]
+        th = (U * sv) @ V.conj().T
+        E = cplx.embed(th).reshape(2 * m, 1, 2 * n, 1)
+        before = dict(cb.calls)
+        al, c, ar, S, disc = cplx.split_two_site(cb, cb.upload(E), trunc_dim=k)
+        assert cb.calls.get("tsplit", 0) == before.get("tsplit", 0) + 1          # the fast path ran
+        A2, Cm, B2 = cb.download(al).reshape(2 * m, 2 * k), cb.download(c), cb.download(ar).reshape(2 * k, 2 * n)
+        assert np.abs(A2.T @ A2 - np.eye(2 * k)).max() < 1e-12 and np.abs(B2 @ B2.T - np.eye(2 * k)).max() < 1e-12
+        assert cplx.structure_defect(A2) < 1e-12 and cplx.structure_defect(B2) < 1e-12
+        assert np.abs(S - sv[:k]).max() < 1e-12
+        rec = cplx.extract(A2 @ Cm @ B2)
+        assert abs(np.linalg.norm(th - rec) - np.linalg.norm(sv[k:])) < 1e-11
