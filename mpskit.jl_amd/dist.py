@@ -265,6 +265,13 @@ class ShardedSiteOp:
         self.n_apply = 0
         self._hac = None
 
+    def agree(self, flag: bool) -> bool:
+        """True iff EVERY rank says True (krylov.eigsolve_sr asks before acting on a convergence decision)."""
+        if self.comm.world == 1 and not self.comm.force_collective:
+            return bool(flag)
+        self.comm.n_agree = getattr(self.comm, "n_agree", 0) + 1
+        return self.comm.all_reduce_scalar(1.0 if flag else 0.0) >= self.comm.world - 0.5
+
     def encode(self, x: DTensor, out: DTensor = None):
         return to_blocked(self.be, x, self.P, out)
 

@@ -122,6 +122,7 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
     # step is discarded: it only wrote basis[k + 2], which the Ritz vector of step k does not involve (at most one wasted
     # matvec per solve, counted in nmv).
     spec = hasattr(be, "orth_step_async") and fixed_matvecs is None
+    agree = getattr(matvec, "agree", None)
 
     def account(kk, h, beta):
         """column kk of the projected matrix is known: eager convergence test of the (kk + 1)-dimensional space"""
@@ -135,7 +136,11 @@ def eigsolve_sr(be: Backend, matvec, x0: DTensor, tol=1e-12, krylovdim=30, maxit
         done_fixed = fixed_matvecs is not None and nmv >= fixed_matvecs
         # breakdown: the Krylov space is invariant (always the case once k reaches the vector-space dimension)
         breakdown = beta <= 1e-13 * max(np.abs(Hk).max(), 1e-300) or kk + 1 >= x0.size
-        return (fixed_matvecs is None and res < tol) or breakdown or done_fixed
+        ok = (fixed_matvecs is None and res < tol) or breakdown or done_fixed
+        # a bond-sharded operator (dist.ShardedSiteOp) makes the ranks AGREE on every data-dependent decision: they hold
+        # bit-identical vectors by construction, the tiny all-reduce is insurance against one of them ever seeing another
+        # rounding (a rank that stops while its peers enter the next all-gather would hang the job)
+        return agree(ok) if (agree is not None and fixed_matvecs is None) else ok
 
     S = ev = None
     for _restart in range(maxiter):

@@ -95,6 +95,7 @@ def _worker(rank, world, port, ret):
         ok_c = abs(Es - Eu) < 1e-10 * abs(Eu) and all(bool((o == t).all()) for o in outs)
         ok_c = ok_c and abs(max(eps_s) - max(eps_u)) < 1e-8 and es.n_transfers == eu.n_transfers
         ok_c = ok_c and comm.n_allgather > ng0 and comm.n_allreduce > nr0
+        ok_c = ok_c and getattr(comm, "n_agree", 0) > 0          # tolerance mode: the ranks agreed on every convergence decision
         # left-environment updates onto a sharded bond use ONE reduce-scatter each (row input -> row output); an all-reduce
         # only remains where the output bond is too small to shard; a right-environment gather is ONE collective
         ok_c = ok_c and comm.n_reduce_scatter > ns0 and (comm.n_reduce_scatter - ns0) + (comm.n_allreduce - nr0) <= es.n_transfers - nt0
