@@ -75,7 +75,8 @@ const char* mpsk_last_error(void);
 int mpsk_ctx_create(int device, mpsk_ctx** out);
 int mpsk_ctx_destroy(mpsk_ctx* ctx);
 int mpsk_ctx_set_stream(mpsk_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = default */
-int mpsk_ctx_set_dtype(mpsk_ctx* ctx, int dtype);              /* scalar type of the slice-less calls (mpsk_dC, ...) */
+int mpsk_ctx_set_dtype(mpsk_ctx* ctx, int dtype);              /* scalar type of the slice-less calls (mpsk_dC, pass-through
+                                                                 * transfers, mpsk_qrpos, mpsk_lqpos, mpsk_tsplit) */
 int mpsk_ctx_get_stream(mpsk_ctx* ctx, void** hip_stream);
 int mpsk_ctx_get_device(mpsk_ctx* ctx, int* device);
 int mpsk_ctx_synchronize(mpsk_ctx* ctx);
