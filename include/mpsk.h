@@ -46,8 +46,10 @@
  *    mpsk_tsplit (max_keep only: trunc_err must be 0) returns complex isometries AL / AR, C lower triangular with a real
  *    positive diagonal and the kept COMPLEX singular values; the real split of the embedding (every value twice, arbitrary
  *    basis inside each pair) only supplies the kept subspace, which is made an embedding again by projecting structured
- *    random vectors on it, with a J-invariant choice inside a cluster that straddles the cut.  The remaining entry points
- *    (mpsk_qrpos2, mpsk_qrlq_pair, mpsk_tsvd, Krylov vector helpers, mpsk_gemm, mpsk_regularize) are fp64 only and ignore
+ *    random vectors on it, with a J-invariant choice inside a cluster that straddles the cut.  mpsk_gemm under MPSK_C128
+ *    multiplies interleaved complex matrices (trans = conjugate transpose, alpha / beta real, leading dimensions in complex
+ *    elements) as ONE real GEMM on the embedded A and the interleaved B: 8 M N K flops, the complex optimum.  The remaining
+ *    entry points (mpsk_qrpos2, mpsk_qrlq_pair, mpsk_tsvd, Krylov vector helpers, mpsk_regularize) are fp64 only and ignore
  *    the ctx dtype: a complex host runs its vector arithmetic on the 2n doubles of an interleaved vector (real inner
  *    products suffice for the Hermitian Lanczos solvers).
  */
@@ -76,7 +78,7 @@ int mpsk_ctx_create(int device, mpsk_ctx** out);
 int mpsk_ctx_destroy(mpsk_ctx* ctx);
 int mpsk_ctx_set_stream(mpsk_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = default */
 int mpsk_ctx_set_dtype(mpsk_ctx* ctx, int dtype);              /* scalar type of the slice-less calls (mpsk_dC, pass-through
-                                                                 * transfers, mpsk_qrpos, mpsk_lqpos, mpsk_tsplit) */
+                                                                 * transfers, mpsk_qrpos, mpsk_lqpos, mpsk_tsplit, mpsk_gemm) */
 int mpsk_ctx_get_stream(mpsk_ctx* ctx, void** hip_stream);
 int mpsk_ctx_get_device(mpsk_ctx* ctx, int* device);
 int mpsk_ctx_synchronize(mpsk_ctx* ctx);

@@ -387,6 +387,23 @@ class Backend:
         check(self.lib.mpsk_qrpos(self.ctx, m, n, A.ptr, m, Q.ptr, m, R.ptr, k), "mpsk_qrpos")
         return Q, R
 
+    def gemm_c(self, A: DTensor, B: DTensor, transA=False, transB=False, alpha=1.0, beta=0.0, out: DTensor = None):
+        """C = alpha op(A) op(B) + beta C on interleaved complex128 matrices (shape (2 rows, cols); op = conjugate transpose;
+        mpsk_gemm under MPSK_C128: the small gauge products AC = AL*C, AL = Q_AC*Q_C' of a complex host)."""
+        ar, ac = A.shape[0] // 2, A.shape[1]
+        br, bc = B.shape[0] // 2, B.shape[1]
+        M, K = (ac, ar) if transA else (ar, ac)
+        K2, N = (bc, br) if transB else (br, bc)
+        assert K == K2
+        out = self.empty(2 * M, N) if out is None else out
+        self._set_dtype(True)
+        try:
+            check(self.lib.mpsk_gemm(self.ctx, int(transA), int(transB), M, N, K, float(alpha), A.ptr, ar, B.ptr, br,
+                                     float(beta), out.ptr, M), "mpsk_gemm (C128)")
+        finally:
+            self._set_dtype(False)
+        return out
+
     def qrpos_c(self, A: DTensor):
         """QRpos of an interleaved complex128 matrix (upload_c layout: shape (2 m, n) = complex m x n): returns Q (2 m, n) and
         R (2 n, n), complex upper triangular with a real positive diagonal (mpsk_qrpos under MPSK_C128)."""

@@ -2032,10 +2032,37 @@ int mpsk_ctx_split_stats(mpsk_ctx* c, int* path, int* iterations, double* residu
   return MPSK_OK;
 }
 
+// complex128 (ctx dtype MPSK_C128): C = alpha op(A) op(B) + beta C on interleaved complex matrices, op = conjugate transpose,
+// alpha / beta real.  An interleaved complex matrix IS the even-column half of its real embedding, and only those columns
+// of the result are wanted:  C_half = op(E_A) . (op(B))_half  -- ONE real GEMM with A embedded (2M x 2K) and B (or its
+// conjugate transpose, materialised) as is: 8 M N K real flops, the complex optimum.
+static int gemm_c128(mpsk_ctx* c, int transA, int transB, int M, int N, int K, double alpha, const void* A, int64_t lda,
+                     const void* B, int64_t ldb, double beta, void* C, int64_t ldc) {
+  HIPCHK(hipSetDevice(c->device));
+  const int ar = transA ? K : M, ac = transA ? M : K;                  // A as stored: ar x ac complex
+  const size_t ea = (size_t)4 * ar * ac, bt = transB ? (size_t)2 * K * N : 0;
+  double* buf = nullptr;
+  if (int rc = cx_scratch(c, 1, sizeof(double) * (ea + bt), &buf)) return rc;
+  double* EA = buf;
+  hipLaunchKernelGGL(cx_embed_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)A, 2 * lda, ar, ac, EA, (int64_t)2 * ar);
+  const double* Bh = (const double*)B;
+  int64_t ldbh = 2 * ldb;
+  if (transB) {                                                        // B stored N x K complex -> B^H (K x N)
+    double* Bt = buf + ea;
+    hipLaunchKernelGGL(cx_ctranspose_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)B, 2 * ldb, N, K, Bt, (int64_t)2 * K);
+    Bh = Bt; ldbh = (int64_t)2 * K;
+  }
+  GemmArgs g = mk(EA, Bh, (double*)C, 2 * M, N, 2 * K, (int64_t)2 * ar, ldbh, 2 * ldc, transA ? 1 : 0, 0);
+  g.alpha = alpha; g.beta = beta;
+  HIPCHK(gemm_f64(g, c->stream));
+  return MPSK_OK;
+}
+
 int mpsk_gemm(mpsk_ctx* c, int transA, int transB, int M, int N, int K, double alpha, const void* A, int64_t lda,
               const void* B, int64_t ldb, double beta, void* C, int64_t ldc) {
   REQUIRE(c && A && B && C, "NULL argument");
   REQUIRE(M > 0 && N > 0 && K > 0, "dimensions must be positive");
+  if (c->dtype == MPSK_C128) return gemm_c128(c, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
   HIPCHK(hipSetDevice(c->device));
   GemmArgs g = mk((const double*)A, (const double*)B, (double*)C, M, N, K, lda, ldb, ldc, transA ? 1 : 0, transB ? 1 : 0);
   g.alpha = alpha; g.beta = beta;

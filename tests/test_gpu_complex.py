@@ -291,3 +291,19 @@ def test_tsplit_complex128_through_the_abi(be, m, n, k):
         assert abs(np.linalg.norm(th - A @ Cm @ B) - best) < 1e-11
         assert abs(disc - best) < 1e-7 + 1e-11 * (best > 1e-6)      # (|theta|^2 - |c|^2 cancels for tiny discarded weights)
         assert np.abs(np.linalg.svd(Cm, compute_uv=False) - sv[:kk]).max() < 1e-12
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(5, 3, 4), (130, 70, 33), (512, 256, 256)])
+def test_gemm_complex128_through_the_abi(be, M, N, K, tA, tB):
+    """mpsk_gemm under MPSK_C128: C = alpha op(A) op(B) + beta C on interleaved complex matrices, op = conjugate transpose
+    (AC = AL*C, AC = C*AR, AL = Q_AC*Q_C' on ComplexF64 tensors: orthoview.jl:99,103, ortho.jl:130) == numpy."""
+    rng = np.random.default_rng(M + N + K + 2 * tA + tB)
+    cr = lambda *sh: rng.standard_normal(sh) + 1j * rng.standard_normal(sh)
+    A = cr(K, M) if tA else cr(M, K)
+    B = cr(N, K) if tB else cr(K, N)
+    C0 = cr(M, N)
+    ref = 0.7 * (A.conj().T if tA else A) @ (B.conj().T if tB else B) - 1.3 * C0
+    out = be.upload_c(C0)
+    be.gemm_c(be.upload_c(A), be.upload_c(B), transA=bool(tA), transB=bool(tB), alpha=0.7, beta=-1.3, out=out)
+    assert np.abs(be.download_c(out) - ref).max() < 1e-13 * K * max(1.0, np.abs(ref).max())
