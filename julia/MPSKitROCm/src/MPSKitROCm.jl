@@ -263,12 +263,16 @@ function regularize!(v::ROCTensor{3}, lvec::ROCTensor{2}, rvec::ROCTensor{2})
 end
 
 # ---- small gauge products  AC = AL*C, C*AR, theta = AC*AR  (orthoview.jl:99,103 ; dmrg.jl:92) ----
+# (complex operands: trans = adjoint, alpha real; mpsk_gemm follows the ctx dtype)
 function mul(A::ROCTensor{2}, B::ROCTensor{2}; transA::Bool=false, transB::Bool=false, alpha=1.0)
     M = transA ? A.dims[2] : A.dims[1]; K = transA ? A.dims[1] : A.dims[2]; N = transB ? B.dims[1] : B.dims[2]
-    Cm = ROCTensor((M, N))
-    check(ccall((:mpsk_gemm, libmpsk[]), Cint,
-        (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Float64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Int64),
-        CTX[], transA, transB, M, N, K, Float64(alpha), A.ptr, A.dims[1], B.ptr, B.dims[1], 0.0, Cm.ptr, M))
+    @assert A.cplx == B.cplx
+    Cm = ROCTensor((M, N); cplx=A.cplx)
+    with_dtype(A.cplx) do
+        check(ccall((:mpsk_gemm, libmpsk[]), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Float64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Int64),
+            CTX[], transA, transB, M, N, K, Float64(alpha), A.ptr, A.dims[1], B.ptr, B.dims[1], 0.0, Cm.ptr, M))
+    end
     return Cm
 end
 
