@@ -103,13 +103,28 @@ def _native_cplx(psi, *envs_):
     return all(e.shape[1] // 2 >= NATIVE_CPLX_MIN_D for e in envs_)
 
 
+def _half_space(psi, op, kind, GR):
+    """Embedded complex state below the native-kernel threshold: the operator still runs on embedded tensors, but the Krylov
+    solvers iterate on HALF-embedded (= interleaved complex) vectors (cplx.HalfSpaceOp: encode . op . decode).  On embedded
+    vectors the real space is twice the complex one -- besides the embeddings it holds the anti-structured tensors X_E sigma_z,
+    on which an embedded operator acts as its partial complex conjugate, with eigenvalues that can lie BELOW the ground state.
+    A solve that restarts from a converged tensor (fixed-budget sweeps: the first residual is rounding noise, normalised to
+    O(1)) drifts into that sector: measured on a converged L = 16, D = 64 Heisenberg chain, sweep energies of -7.13 against a
+    ground-state energy of -6.9117 (tools/native_vs_embedded.py).  On half vectors the sector does not exist."""
+    if not getattr(psi, "cplx", False):
+        return op
+    from .cplx import HalfSpaceOp
+    return HalfSpaceOp(psi.be, op, kind, GR.shape[1] // 2)
+
+
 def ddC(pos, psi, H, envs):  # ∂∂C  derivatives.jl:34-36
     if _is_lazy(H, envs):
         return _lazy(ddC, pos, psi, H, envs)
     if _native_cplx(psi, envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi)):
         from .cplx import HalfEmbeddedOp
         return HalfEmbeddedOp(psi.be, "C", [], envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi))
-    return MPO_ddC(psi.be, envs.leftenv(pos + 1, psi), envs.rightenv(pos, psi))
+    GR = envs.rightenv(pos, psi)
+    return _half_space(psi, MPO_ddC(psi.be, envs.leftenv(pos + 1, psi), GR), "C", GR)
 
 
 def ddAC(pos, psi, H, envs):  # ∂∂AC  derivatives.jl:44-46
@@ -122,7 +137,8 @@ def ddAC(pos, psi, H, envs):  # ∂∂AC  derivatives.jl:44-46
     if _native_cplx(psi, envs.leftenv(pos, psi), envs.rightenv(pos, psi)):
         from .cplx import HalfEmbeddedOp
         return HalfEmbeddedOp(psi.be, "AC", [opp], envs.leftenv(pos, psi), envs.rightenv(pos, psi))
-    return MPO_ddAC(psi.be, opp, envs.leftenv(pos, psi), envs.rightenv(pos, psi))
+    GR = envs.rightenv(pos, psi)
+    return _half_space(psi, MPO_ddAC(psi.be, opp, envs.leftenv(pos, psi), GR), "AC", GR)
 
 
 def ddAC2(pos, psi, H, envs):  # ∂∂AC2  derivatives.jl:55-58
@@ -133,4 +149,5 @@ def ddAC2(pos, psi, H, envs):  # ∂∂AC2  derivatives.jl:55-58
     if _native_cplx(psi, envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi)):
         from .cplx import HalfEmbeddedOp
         return HalfEmbeddedOp(psi.be, "AC2", [o1, o2], envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi))
-    return MPO_ddAC2(psi.be, o1, o2, envs.leftenv(pos, psi), envs.rightenv(pos + 1, psi))
+    GR = envs.rightenv(pos + 1, psi)
+    return _half_space(psi, MPO_ddAC2(psi.be, o1, o2, envs.leftenv(pos, psi), GR), "AC2", GR)

@@ -1,0 +1,243 @@
+"""complex128 finite MPS on INTERLEAVED storage: states, environments and the one-site drivers entirely on the MPSK_C128 entry
+points of the C ABI (include/mpsk.h) -- mpsk_hac_* / mpsk_dC / mpsk_transfer_* (native complex kernels) and, since round 3,
+mpsk_qrpos / mpsk_lqpos / mpsk_gemm under mpsk_ctx_set_dtype(MPSK_C128).  A site tensor A[Dl, d, Dr] of complex numbers is ONE
+device buffer of 2 Dl d Dr doubles in Julia's Array{ComplexF64} layout (shape (2 Dl, d, Dr) as a real tensor): 2x the memory of
+a real state, where the bond-embedded states of cplx.py take 4x and run their transfers at 8x the real flops.
+
+This module is the proof that a complex host needs nothing but the C ABI (it is what a Julia `ROCTensor{ComplexF64}` backend
+would do): the state is kept in explicit mixed-canonical form (sites left of the centre left-orthonormal,
+right of it right-orthonormal), which is all the one-site algorithms need --
+    find_groundstate (DMRG, dmrg.jl:22-55)   ->  NativeFiniteMPS + dmrg_sweep / dmrg
+    timestep (TDVP, tdvp.jl:61-94)           ->  tdvp_step
+The lazy-gauge FiniteMPS of states.py (all drivers, two-site algorithms, infinite systems, excitations) stays on the embedded
+representation; the Krylov solvers are shared (real inner products on the 2n doubles of an interleaved vector are all a
+Hermitian Lanczos / Arnoldi iteration needs, and multiplication by i is mpsk_vtimes_i)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .backend import Backend, DTensor
+from . import krylov
+from .cplx import HalfEmbeddedOp
+
+
+def _mat(t: DTensor, rows2, cols):
+    return t.reshape(rows2, cols)
+
+
+class NativeFiniteMPS:
+    """finite MPS with interleaved complex128 site tensors in mixed-canonical form around `center` (which holds AC)."""
+
+    def __init__(self, tensors, be: Backend, normalize=True):
+        self.be = be
+        self.A = [be.upload_c(np.asarray(t, dtype=np.complex128)) for t in tensors]     # (2 Dl, d, Dr) each
+        self.N = len(self.A)
+        self.center = self.N - 1
+        for i in range(self.N - 1, 0, -1):                     # right-canonicalise: A_i = L Q, A_{i-1} <- A_{i-1} L
+            self._shift_left(i)
+        if normalize:
+            be.scal(1.0 / be.norm(self.A[0]), self.A[0])
+
+    def __len__(self):
+        return self.N
+
+    def dims(self, i):
+        Dl2, d, Dr = self.A[i].shape
+        return Dl2 // 2, d, Dr
+
+    def _shift_right(self, i):
+        """centre i -> i + 1:  AC_i = AL C (QRpos),  AC_{i+1} = C AR_{i+1}   (orthoview.jl:49-60, :99)"""
+        be = self.be
+        Dl, d, Dr = self.dims(i)
+        Q, R = be.qrpos_c(_mat(self.A[i], 2 * Dl * d, Dr))
+        k = R.shape[1]
+        self.A[i] = Q.reshape(2 * Dl, d, k)
+        Dn, dn, Drn = self.dims(i + 1)
+        nxt = be.gemm_c(R, _mat(self.A[i + 1], 2 * Dn, dn * Drn))
+        self.A[i + 1] = nxt.reshape(2 * k, dn, Drn)
+        self.center = i + 1
+        return R
+
+    def _shift_left(self, i):
+        """centre i -> i - 1:  AC_i = C AR (LQpos),  AC_{i-1} = AL_{i-1} C   (orthoview.jl:61-72, :103)"""
+        be = self.be
+        Dl, d, Dr = self.dims(i)
+        Lm, Q = be.lqpos_c(_mat(self.A[i], 2 * Dl, d * Dr))
+        k = Lm.shape[1]
+        self.A[i] = Q.reshape(2 * k, d, Dr)
+        Dp, dp, Drp = self.dims(i - 1)
+        prv = be.gemm_c(_mat(self.A[i - 1], 2 * Dp * dp, Drp), Lm)
+        self.A[i - 1] = prv.reshape(2 * Dp, dp, k)
+        self.center = i - 1
+        return Lm
+
+    def move_center(self, pos):
+        while self.center < pos:
+            self._shift_right(self.center)
+        while self.center > pos:
+            self._shift_left(self.center)
+
+    def norm(self):
+        return self.be.norm(self.A[self.center])
+
+    def to_host(self):
+        """complex host tensors (mixed-canonical around the current centre)."""
+        return [self.be.download_c(t) for t in self.A]
+
+    def bytes(self):
+        return 8 * sum(t.size for t in self.A)
+
+    def copy(self):
+        out = object.__new__(NativeFiniteMPS)
+        out.be, out.N, out.center = self.be, self.N, self.center
+        out.A = [self.be.copy(t) for t in self.A]
+        return out
+
+
+def _boundary(be, chis, D, active):
+    """FinEnv.jl:49-67: identity on the active level, zeros elsewhere -- complex interleaved slabs (W, 2 D, D)."""
+    blocks = []
+    for i, chi in enumerate(chis):
+        b = np.zeros((D, chi, D), dtype=np.complex128)
+        if i == active:
+            for k in range(chi):
+                b[:, k, :] = np.eye(D)
+        blocks.append(b)
+    return be.upload_env_c(blocks)
+
+
+class NativeFinEnv:
+    """left / right environments of a NativeFiniteMPS (FinEnv.jl:9-145), interleaved complex slabs (W, 2 Dbra, Dket); valid
+    for sites strictly left / right of the centre and refreshed as the centre moves (the drivers below move it one site at
+    a time and call `extend_left` / `extend_right`)."""
+
+    def __init__(self, psi: NativeFiniteMPS, H):
+        be = self.be = psi.be
+        L = self.L = len(psi)
+        self.opp = [HalfEmbeddedOp._cslice(be, H[i]) for i in range(L)]
+        self.real_opp = [H[i] for i in range(L)]
+        odim = H.odim
+        self.GL = [_boundary(be, self.real_opp[0].chil, psi.dims(0)[0], 0)] + [None] * L
+        self.GR = [None] * L + [_boundary(be, self.real_opp[L - 1].chir, psi.dims(L - 1)[2], odim - 1)]
+        self.n_transfers = 0
+        c = psi.center
+        for j in range(L - 1, c, -1):
+            self.extend_right(psi, j)
+        for j in range(0, c):
+            self.extend_left(psi, j)
+
+    def extend_left(self, psi, j):
+        """GL[j + 1] from GL[j] and the left-orthonormal A[j]  (FinEnv.jl:131-145, transfer.jl:105-110)"""
+        self.GL[j + 1] = self.be.transfer_left(self.opp[j], self.GL[j], psi.A[j], psi.A[j])
+        self.n_transfers += 1
+
+    def extend_right(self, psi, j):
+        """GR[j] from GR[j + 1] and the right-orthonormal A[j]  (FinEnv.jl:114-129)"""
+        self.GR[j] = self.be.transfer_right(self.opp[j], self.GR[j + 1], psi.A[j], psi.A[j])
+        self.n_transfers += 1
+
+    def bytes(self):
+        return 8 * sum(t.size for t in self.GL + self.GR if t is not None)
+
+
+class _HAC:
+    """H_AC of the centre site on interleaved vectors (derivatives.jl:77-93): prepared operator, one call per application."""
+
+    def __init__(self, be, envs, pos):
+        self.h = be.hac_create(envs.opp[pos], envs.GL[pos], envs.GR[pos + 1])
+
+    def __call__(self, x, out=None):
+        return self.h.apply(x, out=out)
+
+
+class _HC:
+    """H_C of the bond right of site pos (derivatives.jl:3-31)."""
+
+    def __init__(self, be, envs, pos):
+        self.be, self.GL, self.GR = be, envs.GL[pos + 1], envs.GR[pos + 1]
+
+    def __call__(self, x, out=None):
+        return self.be.dC(self.GL, self.GR, x, out=out, cplx=True)
+
+
+def energy(psi: NativeFiniteMPS, envs: NativeFinEnv):
+    """<psi|H|psi> / <psi|psi> at the current centre (Re <AC, H_AC AC>; the imaginary part vanishes for Hermitian H)."""
+    be = psi.be
+    ac = psi.A[psi.center]
+    return be.dot(ac, _HAC(be, envs, psi.center)(ac)) / be.dot(ac, ac)
+
+
+def dmrg_sweep(psi: NativeFiniteMPS, H, envs: NativeFinEnv, eigalg, ws=None):
+    """One DMRG sweep, pos in [1:L-1; L:-1:2] (dmrg.jl:33-38): eigsolve with H_AC at the centre, QRpos / LQpos to the next
+    site, one environment transfer.  Starts and ends with the centre at site 0.  Returns the energy after the sweep."""
+    be, L = psi.be, len(psi)
+    ws = krylov.KrylovWorkspace(be) if ws is None else ws
+    psi.move_center(0)
+
+    def solve(pos):
+        h = _HAC(be, envs, pos)
+        _, vec, _, _ = krylov.eigsolve_sr(be, h, psi.A[pos], tol=eigalg.tol, krylovdim=eigalg.krylovdim,
+                                          maxiter=eigalg.maxiter, fixed_matvecs=eigalg.fixed_matvecs, ws=ws)
+        psi.A[pos] = vec
+
+    for pos in range(0, L - 1):
+        solve(pos)
+        psi._shift_right(pos)
+        envs.extend_left(psi, pos)
+    for pos in range(L - 1, 0, -1):
+        solve(pos)
+        psi._shift_left(pos)
+        envs.extend_right(psi, pos)
+    return energy(psi, envs)
+
+
+def dmrg(psi: NativeFiniteMPS, H, eigalg, maxiter=10, tol=1e-10, envs=None, verbose=False):
+    """find_groundstate(psi, H, DMRG(...)) on interleaved complex storage: sweeps until the energy change is below tol."""
+    envs = NativeFinEnv(psi, H) if envs is None else envs
+    ws = krylov.KrylovWorkspace(psi.be)
+    E_old, log = np.inf, []
+    for it in range(1, maxiter + 1):
+        E = dmrg_sweep(psi, H, envs, eigalg, ws)
+        log.append((it, E))
+        if verbose:
+            print(f"DMRG (native complex) {it:3d}: obj = {E:+.12e}")
+        if abs(E - E_old) <= tol * max(1.0, abs(E)):
+            break
+        E_old = E
+    return psi, envs, log
+
+
+def tdvp_step(psi: NativeFiniteMPS, H, envs: NativeFinEnv, t, dt, alg, ws=None):
+    """timestep!(psi, H, t, dt, TDVP())  (tdvp.jl:61-94): forward integration of AC by dt / 2, backward integration of the bond
+    matrix, left to right and back; any complex dt (real time: exp(-i dt H))."""
+    from .algorithms import _integrate_embedded
+    be, L = psi.be, len(psi)
+    ws = krylov.KrylovWorkspace(be) if ws is None else ws
+    psi.move_center(0)
+    fwd, bwd = -1j * complex(dt) / 2, 1j * complex(dt) / 2
+    for i in range(L - 1):
+        psi.A[i] = _integrate_embedded(be, _HAC(be, envs, i), psi.A[i], fwd, alg, ws)
+        Dl, d, Dr = psi.dims(i)
+        Q, R = be.qrpos_c(_mat(psi.A[i], 2 * Dl * d, Dr))
+        psi.A[i] = Q.reshape(2 * Dl, d, R.shape[1])
+        envs.extend_left(psi, i)
+        C = _integrate_embedded(be, _HC(be, envs, i), R, bwd, alg, ws)
+        Dn, dn, Drn = psi.dims(i + 1)
+        psi.A[i + 1] = be.gemm_c(C, _mat(psi.A[i + 1], 2 * Dn, dn * Drn)).reshape(2 * C.shape[0] // 2, dn, Drn)
+        psi.center = i + 1
+    psi.A[L - 1] = _integrate_embedded(be, _HAC(be, envs, L - 1), psi.A[L - 1], fwd, alg, ws)
+    for i in range(L - 1, 0, -1):
+        psi.A[i] = _integrate_embedded(be, _HAC(be, envs, i), psi.A[i], fwd, alg, ws)
+        Dl, d, Dr = psi.dims(i)
+        Lm, Q = be.lqpos_c(_mat(psi.A[i], 2 * Dl, d * Dr))
+        psi.A[i] = Q.reshape(2 * Lm.shape[1], d, Dr)
+        envs.extend_right(psi, i)
+        # the bond matrix between i - 1 and i: H_C with GL[i] and GR[i]
+        hc = _HC.__new__(_HC)
+        hc.be, hc.GL, hc.GR = be, envs.GL[i], envs.GR[i]
+        C = _integrate_embedded(be, hc, Lm, bwd, alg, ws)
+        Dp, dp, Drp = psi.dims(i - 1)
+        psi.A[i - 1] = be.gemm_c(_mat(psi.A[i - 1], 2 * Dp * dp, Drp), C).reshape(2 * Dp, dp, C.shape[1])
+        psi.center = i - 1
+    psi.A[0] = _integrate_embedded(be, _HAC(be, envs, 0), psi.A[0], fwd, alg, ws)
+    return psi, envs

@@ -307,3 +307,85 @@ def test_gemm_complex128_through_the_abi(be, M, N, K, tA, tB):
     out = be.upload_c(C0)
     be.gemm_c(be.upload_c(A), be.upload_c(B), transA=bool(tA), transB=bool(tB), alpha=0.7, beta=-1.3, out=out)
     assert np.abs(be.download_c(out) - ref).max() < 1e-13 * K * max(1.0, np.abs(ref).max())
+
+
+def _vec(tensors):
+    """state vector of an open-boundary MPS given as [Dl, d, Dr] tensors (any gauge)"""
+    v = tensors[0]
+    for t in tensors[1:]:
+        v = np.tensordot(v, t, axes=([-1], [0]))
+    return v.reshape(-1)
+
+
+def test_native_interleaved_dmrg_and_tdvp_match_the_oracle(be):
+    """native_cplx: complex128 states on INTERLEAVED storage, every step through the MPSK_C128 entry points of the C ABI
+    (prepared operator, mpsk_dC, transfers, mpsk_qrpos / mpsk_lqpos / mpsk_gemm complex).  One-site DMRG sweeps follow the
+    oracle's complex128 run sweep by sweep (dmrg.jl:22-55); a real-time TDVP step (tdvp.jl:61-94) lands on the oracle's
+    state (overlap 1 - 1e-10, energy conserved); the state takes 2x the memory of a real one (the embedded host: 4x)."""
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import native_cplx as nc
+    rng = np.random.default_rng(5)
+    L, d, D = 8, 2, 12
+    dims = mo.FiniteMPS.random(L, d, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i])) + 1j * rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i]))
+          for i in range(L)]
+    H = mk.heisenberg_XXX(0.5, be=be)
+    Ho = mo.heisenberg_mpo(0.5)
+    psi = nc.NativeFiniteMPS(As, be)
+    assert psi.bytes() == 16 * sum(int(np.prod(a.shape)) for a in As)
+    assert abs(psi.norm() - 1.0) < 1e-13
+    # the right-canonical form built through mpsk_lqpos / mpsk_gemm (C128) is the input state
+    v0 = _vec(As); v0 /= np.linalg.norm(v0)
+    assert abs(abs(np.vdot(v0, _vec(psi.to_host()))) - 1.0) < 1e-12
+    envs = nc.NativeFinEnv(psi, H)
+    po = mo.FiniteMPS(As, normalize=True)
+    eo = mo.FinEnv(po, Ho)
+    assert abs(nc.energy(psi, envs) - float(np.real(np.sum(mo.expectation_value(po, Ho, eo))))) < 1e-11
+    eig = mk.Arnoldi(tol=1e-12, krylovdim=20, maxiter=50)
+    for sweep in range(3):
+        E = nc.dmrg_sweep(psi, H, envs, eig)
+        po, eo, _, log = mo.dmrg(po, Ho, maxiter=1, eig_tol=1e-12, krylovdim=20, eig_maxiter=50, envs=None)
+        eo = mo.FinEnv(po, Ho)
+        assert abs(E - log[-1][1]) < 1e-9 * abs(E), (sweep, E, log[-1][1])
+    E0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
+    assert E0 - 1e-9 <= E <= E0 + 1e-3 * abs(E0)
+    # real-time TDVP step from a fresh random complex state
+    psi = nc.NativeFiniteMPS(As, be)
+    envs = nc.NativeFinEnv(psi, H)
+    po = mo.FiniteMPS(As, normalize=True)
+    e_before = nc.energy(psi, envs)
+    alg = mk.TDVP(tol=1e-12, krylovdim=20)
+    psi, envs = nc.tdvp_step(psi, H, envs, 0.0, 0.05, alg)
+    po2, _ = mo.tdvp_timestep(po, Ho, 0.0, 0.05, tol=1e-12, krylovdim=20)
+    vo = mo.mps_to_vector(po2)
+    vn = _vec(psi.to_host())
+    assert abs(np.linalg.norm(vn) - 1.0) < 1e-10
+    assert abs(abs(np.vdot(vo, vn)) - 1.0) < 1e-9
+    assert abs(nc.energy(psi, envs) - e_before) < 1e-8
+
+
+def test_fixed_budget_sweeps_on_a_converged_complex_state_stay_variational_gpu(be):
+    """The GPU twin of tests/test_host_logic_cpu.py::test_fixed_budget_sweeps_on_a_converged_complex_state_stay_variational
+    at the size where it was found (L = 16, D = 64, 8 matvecs per site: -7.13 against a converged -6.9117 before the Krylov
+    solvers of embedded complex states moved to half-embedded vectors), on the embedded host state AND the interleaved one."""
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import algorithms as alg, krylov, native_cplx as nc
+    L, D = 16, 64
+    H = mk.heisenberg_XXX(0.5, be=be)
+    ref = mk.FiniteMPS.random(L, 2, D, np.random.default_rng(5), be=be, dtype=complex)
+    As = [ref.download(ref.AL(i)) for i in range(L - 1)] + [ref.download(ref.AC(L - 1))]
+    ws = krylov.KrylovWorkspace(be)
+    pe = mk.FiniteMPS(As, normalize=True, be=be); ee = mk.FinEnv(pe, H)
+    pn = nc.NativeFiniteMPS(As, be); en = nc.NativeFinEnv(pn, H)
+    tol = mk.Arnoldi(tol=1e-12, krylovdim=30, maxiter=100)
+    for _ in range(2):
+        alg.dmrg_sweep(pe, H, ee, tol, ws)
+        En = nc.dmrg_sweep(pn, H, en, tol, ws)
+    Ec = float(np.sum(mk.expectation_value(pe, H, ee)))
+    assert abs(Ec - En) < 1e-10
+    fixed = mk.Arnoldi(fixed_matvecs=8, krylovdim=8)
+    for _ in range(2):
+        alg.dmrg_sweep(pe, H, ee, fixed, ws)
+        En = nc.dmrg_sweep(pn, H, en, fixed, ws)
+        Ee = float(np.sum(mk.expectation_value(pe, H, ee)))
+        assert abs(Ee - Ec) < 1e-8 and abs(En - Ec) < 1e-8, (Ee, En, Ec)

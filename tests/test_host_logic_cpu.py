@@ -619,3 +619,31 @@ def test_structured_split_fast_path_host_logic(cb):
         assert np.abs(S - sv[:k]).max() < 1e-12
         rec = cplx.extract(A2 @ Cm @ B2)
         assert abs(np.linalg.norm(th - rec) - np.linalg.norm(sv[k:])) < 1e-11
+
+
+def test_fixed_budget_sweeps_on_a_converged_complex_state_stay_variational(cb):
+    """Embedded complex states: a fixed-budget eigensolve that restarts from a CONVERGED tensor normalises rounding noise to
+    O(1); on embedded Krylov vectors that noise populates the anti-structured sector, where the embedded operator has
+    eigenvalues below the ground state, and the sweep energy dropped below the exact ground-state energy (GPU, L = 16,
+    D = 64: -7.13 against -6.9117).  The solvers now iterate on half-embedded vectors (derivatives._half_space): the energy
+    stays at the converged value and above the ED bound."""
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import algorithms as alg, krylov
+    rng = np.random.default_rng(11)
+    L, d, D = 8, 2, 8
+    dims = mo.FiniteMPS.random(L, d, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i])) + 1j * rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i]))
+          for i in range(L)]
+    H = mk.heisenberg_XXX(0.5, be=cb)
+    psi = mk.FiniteMPS(As, normalize=True, be=cb)
+    envs = mk.FinEnv(psi, H)
+    ws = krylov.KrylovWorkspace(cb)
+    for _ in range(3):
+        alg.dmrg_sweep(psi, H, envs, mk.Arnoldi(tol=1e-12, krylovdim=20, maxiter=50), ws)
+    Ec = float(np.sum(mk.expectation_value(psi, H, envs)))
+    E0 = np.linalg.eigvalsh(mo.dense_hamiltonian(mo.heisenberg_mpo(0.5), L))[0]
+    assert E0 - 1e-10 <= Ec <= E0 + 1e-3 * abs(E0)
+    for _ in range(3):
+        alg.dmrg_sweep(psi, H, envs, mk.Arnoldi(fixed_matvecs=6, krylovdim=6), ws)
+        E = float(np.sum(mk.expectation_value(psi, H, envs)))
+        assert E >= E0 - 1e-9 and abs(E - Ec) < 1e-8, (E, Ec, E0)
