@@ -17,3 +17,4 @@ from .excitations import excitations, FiniteExcited, ProjectionOperator  # noqa:
 from .quasiparticle import QuasiparticleAnsatz, LeftGaugedQP  # noqa: F401,E402
 from .toolbox import (variance, entropy, entanglement_spectrum, transfer_spectrum, marek_gap, correlation_length,  # noqa: F401,E402
                       exact_diagonalization)
+from . import native_cplx  # noqa: F401,E402   (complex128 states on interleaved storage: NativeFiniteMPS, dmrg, tdvp_step)
