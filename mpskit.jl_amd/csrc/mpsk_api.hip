@@ -1927,7 +1927,6 @@ static int tsplit_c128(mpsk_ctx* c, int m, int n, const void* theta, int ldt, in
   REQUIRE(m > 0 && n > 0, "dimensions must be positive");
   REQUIRE(trunc_err == 0.0, "complex mpsk_tsplit truncates by max_keep only (trunc_err must be 0)");
   const int kfull = m < n ? m : n;
-  REQUIRE(2 * kfull > 64, "mpsk_tsplit needs 2 min(m, n) > 64 for complex tensors");
   const int k = (max_keep > 0 && max_keep < kfull) ? max_keep : kfull;
   REQUIRE(ldt >= m && ldal >= m && ldc >= k && ldar >= k, "leading dimension too small");
   HIPCHK(hipSetDevice(c->device));
@@ -1949,7 +1948,11 @@ static int tsplit_c128(mpsk_ctx* c, int m, int n, const void* theta, int ldt, in
     if (req > kE) req = kE;
     int kk = 0;
     double dn = 0.0;
-    if (int rc = tsplit_f64(c, m2, n2, E, m2, req, 0.0, ALe, m2, Ce, kE, ARe, kE, Se, &kk, &dn)) return rc;
+    if (kE > 64) {
+      if (int rc = tsplit_f64(c, m2, n2, E, m2, req, 0.0, ALe, m2, Ce, kE, ARe, kE, Se, &kk, &dn)) return rc;
+    } else {        // small tensors: the full decomposition (mpsk_tsvd has no size floor); only its left vectors are used
+      if (int rc = mpsk_tsvd(c, m2, n2, E, m2, ALe, m2, Se, ARe, kE, req, 0.0, &kk, &dn)) return rc;
+    }
     have = kk;
     hs.resize(have);
     HIPCHK(hipMemcpyAsync(hs.data(), Se, sizeof(double) * have, hipMemcpyDeviceToHost, c->stream));

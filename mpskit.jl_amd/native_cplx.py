@@ -8,6 +8,7 @@ This module is the proof that a complex host needs nothing but the C ABI (it is 
 would do): the state is kept in explicit mixed-canonical form (sites left of the centre left-orthonormal,
 right of it right-orthonormal), which is all the one-site algorithms need --
     find_groundstate (DMRG, dmrg.jl:22-55)   ->  NativeFiniteMPS + dmrg_sweep / dmrg
+    find_groundstate (DMRG2, dmrg.jl:80-137) ->  dmrg2_sweep   (mpsk_dAC2 complex, mpsk_tsplit under MPSK_C128)
     timestep (TDVP, tdvp.jl:61-94)           ->  tdvp_step
 The lazy-gauge FiniteMPS of states.py (all drivers, two-site algorithms, infinite systems, excitations) stays on the embedded
 representation; the Krylov solvers are shared (real inner products on the 2n doubles of an interleaved vector are all a
@@ -241,3 +242,58 @@ def tdvp_step(psi: NativeFiniteMPS, H, envs: NativeFinEnv, t, dt, alg, ws=None):
         psi.center = i - 1
     psi.A[0] = _integrate_embedded(be, _HAC(be, envs, 0), psi.A[0], fwd, alg, ws)
     return psi, envs
+
+
+def _two_site(be, left: DTensor, right: DTensor):
+    """theta[a, s1, b, s2] = sum_m left[a, s1, m] right[m, s2, b] on interleaved tensors (dmrg.jl:92 / :108): d2 complex GEMMs
+    on strided views of `right` (mpsk_gemm under MPSK_C128; leading dimensions and offsets in complex elements)."""
+    Dl, d1, Dm = left.shape[0] // 2, left.shape[1], left.shape[2]
+    _, d2, Dr = right.shape
+    theta = be.empty(2 * Dl, d1, Dr, d2)
+    be._set_dtype(True)
+    try:
+        for s2 in range(d2):
+            be.gemm_raw(False, False, Dl * d1, Dr, Dm, 1.0, left.ptr, Dl * d1, right.ptr + 16 * s2 * Dm, Dm * d2, 0.0,
+                        theta.ptr + 16 * s2 * Dl * d1 * Dr, Dl * d1)
+    finally:
+        be._set_dtype(False)
+    return theta
+
+
+def dmrg2_sweep(psi: NativeFiniteMPS, H, envs: NativeFinEnv, eigalg, trunc_dim, ws=None):
+    """One two-site DMRG sweep (dmrg.jl:86-120) on interleaved storage: theta = AC AR, eigsolve with H_AC2 (mpsk_dAC2 complex),
+    al, c, ar = tsvd!(theta; trunc = truncdim(D)) through mpsk_tsplit under MPSK_C128, normalize!(c).  Centre at site 0 before
+    and after.  Returns the energy after the sweep."""
+    be, L = psi.be, len(psi)
+    ws = krylov.KrylovWorkspace(be) if ws is None else ws
+    psi.move_center(0)
+
+    def update(pos, theta):
+        h1, h2, GL, GR = envs.opp[pos], envs.opp[pos + 1], envs.GL[pos], envs.GR[pos + 2]
+        op = lambda x, out=None: be.dAC2(h1, h2, GL, GR, x, out=out)
+        _, new, _, _ = krylov.eigsolve_sr(be, op, theta, tol=eigalg.tol, krylovdim=eigalg.krylovdim, maxiter=eigalg.maxiter,
+                                          fixed_matvecs=eigalg.fixed_matvecs, ws=ws)
+        Dl2, d1, Dr, d2 = new.shape
+        al, c, arm, _, _ = be.tsplit_c(new.reshape(Dl2 * d1, Dr * d2), max_keep=trunc_dim)
+        k = c.shape[1]
+        be.scal(1.0 / be.norm(c), c)                                     # normalize!(c)
+        ar = be.empty(2 * k, d2, Dr)                                     # ar[k, s2, b] = arm[k, (b, s2)]
+        for s2 in range(d2):
+            be.copy2d(2 * k, Dr, arm.ptr + 8 * s2 * 2 * k * Dr, 2 * k, ar.ptr + 8 * s2 * 2 * k, 2 * k * d2)
+        return al.reshape(Dl2, d1, k), c, ar
+
+    for pos in range(0, L - 1):
+        al, c, ar = update(pos, _two_site(be, psi.A[pos], psi.A[pos + 1]))
+        k, d2, Dr = c.shape[1], ar.shape[1], ar.shape[2]
+        psi.A[pos] = al
+        psi.A[pos + 1] = be.gemm_c(c, ar.reshape(2 * k, d2 * Dr)).reshape(2 * k, d2, Dr)      # AC_{pos+1} = c ar
+        psi.center = pos + 1
+        envs.extend_left(psi, pos)
+    for pos in range(L - 2, -1, -1):
+        al, c, ar = update(pos, _two_site(be, psi.A[pos], psi.A[pos + 1]))
+        Dl2, d1, k = al.shape
+        psi.A[pos + 1] = ar
+        psi.A[pos] = be.gemm_c(al.reshape(Dl2 * d1, k), c).reshape(Dl2, d1, k)                # AC_pos = al c
+        psi.center = pos
+        envs.extend_right(psi, pos + 1)
+    return energy(psi, envs)

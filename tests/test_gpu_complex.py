@@ -265,7 +265,8 @@ def test_qrpos_lqpos_complex128_through_the_abi(be, m, n):
             assert np.abs(L - Lo).max() < 1e-12 * np.abs(Lo).max() and np.abs(Ql - Qlo).max() < 1e-12
 
 
-@pytest.mark.parametrize("m,n,k", [(192, 160, 40), (160, 192, 40), (256, 256, 64), (96, 80, 0), (512, 512, 128)])
+@pytest.mark.parametrize("m,n,k", [(192, 160, 40), (160, 192, 40), (256, 256, 64), (96, 80, 0), (512, 512, 128), (20, 16, 6),
+                                   (24, 24, 12)])
 def test_tsplit_complex128_through_the_abi(be, m, n, k):
     """mpsk_tsplit under MPSK_C128 (tsvd!(theta; trunc = truncdim(k)) of a ComplexF64 two-site tensor, dmrg.jl:96-104):
     al / ar complex isometries, c lower triangular with a real positive diagonal, the kept values are the complex singular
@@ -389,3 +390,27 @@ def test_fixed_budget_sweeps_on_a_converged_complex_state_stay_variational_gpu(b
         En = nc.dmrg_sweep(pn, H, en, fixed, ws)
         Ee = float(np.sum(mk.expectation_value(pe, H, ee)))
         assert abs(Ee - Ec) < 1e-8 and abs(En - Ec) < 1e-8, (Ee, En, Ec)
+
+
+def test_native_interleaved_two_site_dmrg_matches_the_oracle(be):
+    """native_cplx.dmrg2_sweep (dmrg.jl:86-120 on interleaved storage: mpsk_dAC2 complex + mpsk_tsplit / mpsk_gemm under
+    MPSK_C128) follows the oracle's complex128 DMRG2 sweep by sweep, from bond dimension 4 up to the truncation bound."""
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import native_cplx as nc
+    rng = np.random.default_rng(8)
+    L, d, D0, D = 8, 2, 4, 12
+    dims = mo.FiniteMPS.random(L, d, D0, np.random.default_rng(0)).bond_dims()
+    As = [rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i])) + 1j * rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i]))
+          for i in range(L)]
+    H, Ho = mk.heisenberg_XXX(0.5, be=be), mo.heisenberg_mpo(0.5)
+    psi = nc.NativeFiniteMPS(As, be)
+    envs = nc.NativeFinEnv(psi, H)
+    po = mo.FiniteMPS(As, normalize=True)
+    eig = mk.Arnoldi(tol=1e-12, krylovdim=20, maxiter=50)
+    for sweep in range(3):
+        E = nc.dmrg2_sweep(psi, H, envs, eig, trunc_dim=D)
+        po, _, _, log = mo.dmrg2(po, Ho, truncdim=D, maxiter=1, eig_tol=1e-12, krylovdim=20, eig_maxiter=50)
+        assert abs(E - log[-1][1]) < 1e-9 * abs(E), (sweep, E, log[-1][1])
+    assert max(psi.dims(i)[2] for i in range(L - 1)) == D
+    E0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
+    assert E0 - 1e-9 <= E <= E0 + 1e-4 * abs(E0)
