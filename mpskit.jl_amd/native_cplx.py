@@ -10,6 +10,7 @@ right of it right-orthonormal), which is all the one-site algorithms need --
     find_groundstate (DMRG, dmrg.jl:22-55)   ->  NativeFiniteMPS + dmrg_sweep / dmrg
     find_groundstate (DMRG2, dmrg.jl:80-137) ->  dmrg2_sweep   (mpsk_dAC2 complex, mpsk_tsplit under MPSK_C128)
     timestep (TDVP, tdvp.jl:61-94)           ->  tdvp_step
+    timestep (TDVP2, tdvp.jl:113-146)        ->  tdvp2_step
 The lazy-gauge FiniteMPS of states.py (all drivers, two-site algorithms, infinite systems, excitations) stays on the embedded
 representation; the Krylov solvers are shared (real inner products on the 2n doubles of an interleaved vector are all a
 Hermitian Lanczos / Arnoldi iteration needs, and multiplication by i is mpsk_vtimes_i)."""
@@ -297,3 +298,46 @@ def dmrg2_sweep(psi: NativeFiniteMPS, H, envs: NativeFinEnv, eigalg, trunc_dim, 
         psi.center = pos
         envs.extend_right(psi, pos + 1)
     return energy(psi, envs)
+
+
+def tdvp2_step(psi: NativeFiniteMPS, H, envs: NativeFinEnv, t, dt, alg, trunc_dim, ws=None):
+    """timestep!(psi, H, t, dt, TDVP2(truncdim(D)))  (tdvp.jl:113-146) on interleaved storage: two-site tensors integrated
+    forward by dt / 2 and split (mpsk_tsplit under MPSK_C128; NO normalisation of c: the evolution is unitary), the new
+    centre integrated backward, left to right and back."""
+    from .algorithms import _integrate_embedded
+    be, L = psi.be, len(psi)
+    ws = krylov.KrylovWorkspace(be) if ws is None else ws
+    psi.move_center(0)
+    fwd, bwd = -1j * complex(dt) / 2, 1j * complex(dt) / 2
+
+    def evolve_and_split(pos, theta):
+        h1, h2, GL, GR = envs.opp[pos], envs.opp[pos + 1], envs.GL[pos], envs.GR[pos + 2]
+        op = lambda x, out=None: be.dAC2(h1, h2, GL, GR, x, out=out)
+        new = _integrate_embedded(be, op, theta, fwd, alg, ws)
+        Dl2, d1, Dr, d2 = new.shape
+        al, c, arm, _, _ = be.tsplit_c(new.reshape(Dl2 * d1, Dr * d2), max_keep=trunc_dim)
+        k = c.shape[1]
+        ar = be.empty(2 * k, d2, Dr)
+        for s2 in range(d2):
+            be.copy2d(2 * k, Dr, arm.ptr + 8 * s2 * 2 * k * Dr, 2 * k, ar.ptr + 8 * s2 * 2 * k, 2 * k * d2)
+        return al.reshape(Dl2, d1, k), c, ar
+
+    for i in range(L - 1):
+        al, c, ar = evolve_and_split(i, _two_site(be, psi.A[i], psi.A[i + 1]))
+        k, d2, Dr = c.shape[1], ar.shape[1], ar.shape[2]
+        psi.A[i] = al
+        psi.A[i + 1] = be.gemm_c(c, ar.reshape(2 * k, d2 * Dr)).reshape(2 * k, d2, Dr)
+        psi.center = i + 1
+        envs.extend_left(psi, i)
+        if i != L - 2:
+            psi.A[i + 1] = _integrate_embedded(be, _HAC(be, envs, i + 1), psi.A[i + 1], bwd, alg, ws)
+    for i in range(L - 1, 0, -1):
+        al, c, ar = evolve_and_split(i - 1, _two_site(be, psi.A[i - 1], psi.A[i]))
+        Dl2, d1, k = al.shape
+        psi.A[i] = ar
+        psi.A[i - 1] = be.gemm_c(al.reshape(Dl2 * d1, k), c).reshape(Dl2, d1, k)
+        psi.center = i - 1
+        envs.extend_right(psi, i)
+        if i != 1:
+            psi.A[i - 1] = _integrate_embedded(be, _HAC(be, envs, i - 1), psi.A[i - 1], bwd, alg, ws)
+    return psi, envs
