@@ -341,3 +341,43 @@ def tdvp2_step(psi: NativeFiniteMPS, H, envs: NativeFinEnv, t, dt, alg, trunc_di
         if i != 1:
             psi.A[i - 1] = _integrate_embedded(be, _HAC(be, envs, i - 1), psi.A[i - 1], bwd, alg, ws)
     return psi, envs
+
+
+# ---- the reference's entry points on interleaved states (same algorithm objects as algorithms.py) ---------------------------
+
+def find_groundstate(psi: NativeFiniteMPS, H, alg, envs: NativeFinEnv = None):
+    """find_groundstate(psi, H, DMRG(...) | DMRG2(...))  (dmrg.jl:22-55, :80-137): sweeps until the energy moves by less than
+    alg.tol (relative) or alg.maxiter is reached.  Returns (psi, envs, |dE| of the last sweep)."""
+    from .algorithms import DMRG, DMRG2
+    envs = NativeFinEnv(psi, H) if envs is None else envs
+    ws = krylov.KrylovWorkspace(psi.be)
+    E_old, delta = np.inf, np.inf
+    for it in range(1, alg.maxiter + 1):
+        if isinstance(alg, DMRG2):
+            if alg.trunc_dim <= 0:
+                raise NotImplementedError("interleaved DMRG2 truncates by trunc_dim (mpsk_tsplit under MPSK_C128: truncdim scheme)")
+            E = dmrg2_sweep(psi, H, envs, alg.eigalg, alg.trunc_dim, ws)
+        elif isinstance(alg, DMRG):
+            E = dmrg_sweep(psi, H, envs, alg.eigalg, ws)
+        else:
+            raise TypeError(f"find_groundstate on interleaved states takes DMRG or DMRG2, not {type(alg).__name__}")
+        delta = abs(E - E_old)
+        if alg.verbosity >= 3:
+            print(f"[ Info: {type(alg).__name__} (interleaved complex) {it:3d}:\tobj = {E:+.12e}\tdE = {delta:.3e}")
+        if delta <= alg.tol * max(1.0, abs(E)):
+            break
+        E_old = E
+    return psi, envs, delta
+
+
+def timestep(psi: NativeFiniteMPS, H, t, dt, alg, envs: NativeFinEnv = None):
+    """timestep(psi, H, t, dt, TDVP() | TDVP2(...))  (tdvp.jl:61-94, :113-146).  Returns (psi, envs)."""
+    from .algorithms import TDVP, TDVP2
+    envs = NativeFinEnv(psi, H) if envs is None else envs
+    if isinstance(alg, TDVP2):
+        if alg.trunc_dim <= 0:
+            raise NotImplementedError("interleaved TDVP2 truncates by trunc_dim (truncdim scheme)")
+        return tdvp2_step(psi, H, envs, t, dt, alg, alg.trunc_dim)
+    if isinstance(alg, TDVP):
+        return tdvp_step(psi, H, envs, t, dt, alg)
+    raise TypeError(f"timestep on interleaved states takes TDVP or TDVP2, not {type(alg).__name__}")

@@ -414,6 +414,13 @@ def test_native_interleaved_two_site_dmrg_matches_the_oracle(be):
     assert max(psi.dims(i)[2] for i in range(L - 1)) == D
     E0 = np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]
     assert E0 - 1e-9 <= E <= E0 + 1e-4 * abs(E0)
+    # the reference-named entry point: DMRG then DMRG2 objects drive the same sweeps to convergence
+    psi2 = nc.NativeFiniteMPS(As, be)
+    psi2, envs2, dE = nc.find_groundstate(psi2, H, mk.DMRG2(tol=1e-10, maxiter=8, trunc_dim=D, eigalg=eig))
+    psi2, envs2, dE = nc.find_groundstate(psi2, H, mk.DMRG(tol=1e-11, maxiter=8, eigalg=eig), envs2)
+    assert dE <= 1e-8 and abs(nc.energy(psi2, envs2) - E0) < 1e-4 * abs(E0)
+    psi2, envs2 = nc.timestep(psi2, H, 0.0, 0.02, mk.TDVP(tol=1e-10), envs2)
+    assert abs(psi2.norm() - 1.0) < 1e-9
 
 
 def test_native_interleaved_tdvp2_matches_the_oracle(be):
