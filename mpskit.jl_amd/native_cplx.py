@@ -96,6 +96,48 @@ class NativeFiniteMPS:
         return out
 
 
+class ComplexMPOHamiltonian:
+    """MPOHamiltonian with ComplexF64 entries (mpohamiltonian.jl:8-31): a periodic list of MPSK_C128 slices.  `data[site]` =
+    {(i, j): scalar | d x d | [chi_i, d, d, chi_j]} with complex values, levels 0 .. odim - 1, H[0, 0] = H[odim-1, odim-1] = 1.
+    (The real MPOHamiltonian of operators.py is accepted by the drivers as well: its slices get complex twins.)"""
+
+    def __init__(self, data, be: Backend, d=None):
+        if isinstance(data, dict):
+            data = [data]
+        self.be, self.period = be, len(data)
+        self.odim = 1 + max(max(i, j) for blk in data for (i, j) in blk)
+        for blk in data:
+            for v in blk.values():
+                if d is None and not np.isscalar(v):
+                    a = np.asarray(v)
+                    d = a.shape[0] if a.ndim == 2 else a.shape[1]
+        self.d = int(d)
+        chis = [[1] * self.odim for _ in range(self.period + 1)]
+        for s_, blk in enumerate(data):
+            for (i, j), v in blk.items():
+                if not np.isscalar(v) and np.asarray(v).ndim == 4:
+                    chis[s_][i], chis[s_ + 1][j] = np.asarray(v).shape[0], np.asarray(v).shape[3]
+        for i in range(self.odim):
+            chis[0][i] = chis[self.period][i] = max(chis[0][i], chis[self.period][i])
+        self.chis, self.slices = chis, []
+        for s_, blk in enumerate(data):
+            blocks = {}
+            for (i, j), v in blk.items():
+                if np.isscalar(v):
+                    if v != 0:
+                        blocks[(i, j)] = complex(v)
+                    continue
+                a = np.asarray(v, dtype=np.complex128)
+                blocks[(i, j)] = a[None, :, :, None] if a.ndim == 2 else a
+            self.slices.append(be.mposlice(self.odim, self.d, chis[s_], chis[s_ + 1], blocks, cplx=True))
+
+    def __getitem__(self, i):
+        return self.slices[i % self.period]
+
+    def __len__(self):
+        return self.period
+
+
 def _boundary(be, chis, D, active):
     """FinEnv.jl:49-67: identity on the active level, zeros elsewhere -- complex interleaved slabs (W, 2 D, D)."""
     blocks = []
@@ -116,11 +158,15 @@ class NativeFinEnv:
     def __init__(self, psi: NativeFiniteMPS, H):
         be = self.be = psi.be
         L = self.L = len(psi)
-        self.opp = [HalfEmbeddedOp._cslice(be, H[i]) for i in range(L)]
-        self.real_opp = [H[i] for i in range(L)]
+        if isinstance(H, ComplexMPOHamiltonian):
+            self.opp = [H[i] for i in range(L)]
+            chil, chir = H.chis[0], H.chis[(L - 1) % H.period + 1]
+        else:                                                   # real MPOHamiltonian: complex twins of its slices
+            self.opp = [HalfEmbeddedOp._cslice(be, H[i]) for i in range(L)]
+            chil, chir = H[0].chil, H[L - 1].chir
         odim = H.odim
-        self.GL = [_boundary(be, self.real_opp[0].chil, psi.dims(0)[0], 0)] + [None] * L
-        self.GR = [None] * L + [_boundary(be, self.real_opp[L - 1].chir, psi.dims(L - 1)[2], odim - 1)]
+        self.GL = [_boundary(be, chil, psi.dims(0)[0], 0)] + [None] * L
+        self.GR = [None] * L + [_boundary(be, chir, psi.dims(L - 1)[2], odim - 1)]
         self.n_transfers = 0
         c = psi.center
         for j in range(L - 1, c, -1):
