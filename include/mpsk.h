@@ -250,6 +250,12 @@ int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, 
  * Buffers: AL m x min(m,n), C min(m,n)^2, AR min(m,n) x n (only the leading k columns / rows are written). */
 int mpsk_tsplit(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
                 void* AL, int ldal, void* C, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm);
+/* Interleaved complex matrix (m x n complex: 2m x n doubles, ldh in doubles) <-> its real 2m x 2n embedding
+ * E[:, 2b] = h_b, E[:, 2b+1] = J h_b, one launch each.  mpsk_cx_half takes the STRUCTURED PART of a nearly embedded matrix
+ * (re = (E00 + E11) / 2, im = (E10 - E01) / 2 per 2 x 2 block).  For hosts that keep complex tensors bond-embedded
+ * (mpskit.jl_amd/cplx.py) and iterate their Krylov solvers on interleaved vectors. */
+int mpsk_cx_embed(mpsk_ctx* ctx, int m, int n, const void* H, int64_t ldh, void* E, int64_t lde);
+int mpsk_cx_half(mpsk_ctx* ctx, int m, int n, const void* E, int64_t lde, void* H, int64_t ldh);
 /* general column-major product C = alpha op(A) op(B) + beta C for the small gauge products
  * AC = AL*C, AC = C*AR, theta = AC*AR, AL = Q_AC*Q_C'  (orthoview.jl:99,103; dmrg.jl:92; ortho.jl:130) */
 int mpsk_gemm(mpsk_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const void* A,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "mpsk_vorth_step": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, c_double_p, c_double_p],
     "mpsk_vorth_step_dev": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_void_p, C.c_void_p],
     "mpsk_vlincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, c_double_p, C.c_void_p],
+    "mpsk_cx_embed": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
+    "mpsk_cx_half": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
     "mpsk_vmultilincomb": [C.c_void_p, C.c_int64, C.c_int, c_void_pp, C.c_int, c_void_pp, c_double_p],
     "mpsk_vnormalize_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mpsk_vnrm2_dev": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],

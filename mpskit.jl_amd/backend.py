@@ -387,6 +387,14 @@ class Backend:
         check(self.lib.mpsk_qrpos(self.ctx, m, n, A.ptr, m, Q.ptr, m, R.ptr, k), "mpsk_qrpos")
         return Q, R
 
+    def cx_embed_raw(self, m, n, h_ptr, ldh, e_ptr, lde):
+        """embedded (2m x 2n) <- interleaved complex (2m x n), one launch (mpsk_cx_embed; leading dimensions in doubles)"""
+        check(self.lib.mpsk_cx_embed(self.ctx, m, n, h_ptr, ldh, e_ptr, lde), "mpsk_cx_embed")
+
+    def cx_half_raw(self, m, n, e_ptr, lde, h_ptr, ldh):
+        """interleaved complex (2m x n) <- structured part of the embedded (2m x 2n), one launch (mpsk_cx_half)"""
+        check(self.lib.mpsk_cx_half(self.ctx, m, n, e_ptr, lde, h_ptr, ldh), "mpsk_cx_half")
+
     def gemm_c(self, A: DTensor, B: DTensor, transA=False, transB=False, alpha=1.0, beta=0.0, out: DTensor = None):
         """C = alpha op(A) op(B) + beta C on interleaved complex128 matrices (shape (2 rows, cols); op = conjugate transpose;
         mpsk_gemm under MPSK_C128: the small gauge products AC = AL*C, AL = Q_AC*Q_C' of a complex host)."""

@@ -84,6 +84,10 @@ class HalfEmbeddedOp:
         environments built from them are no embeddings there.  Taking e_0 alone made the native operator non-Hermitian
         in those directions (real-time TDVP at D = 512 from a random state: energy drift 3e-4, norm 0.9995); the
         structured part of a symmetric environment is Hermitian, so the evolution stays unitary."""
+        if hasattr(be, "cx_half_raw"):               # one launch on the device backend
+            ev = be.empty(rows, ncols) if out is None else out
+            be.cx_half_raw(rows // 2, ncols, src_ptr, rows, ev.ptr, rows)
+            return ev
         ev = be.empty(rows, ncols)
         od = be.empty(rows, ncols)
         be.copy2d(rows, ncols, src_ptr, 2 * rows, ev.ptr, rows)                   # e_0 columns
@@ -139,6 +143,10 @@ class HalfEmbeddedOp:
         rows, n2, tail = self._geom(full)
         out = be.empty(*full) if out is None else out
         n = n2 // 2
+        if hasattr(be, "cx_embed_raw"):                  # one launch per trailing index on the device backend
+            for j in range(tail):
+                be.cx_embed_raw(rows // 2, n, xh.ptr + 8 * j * rows * n, rows, out.ptr + 8 * j * rows * n2, rows)
+            return out
         jx = be.times_i(xh)                              # J x: (re, im) -> (-im, re) on every row pair
         for j in range(tail):
             be.copy2d(rows, n, xh.ptr + 8 * j * rows * n, rows, out.ptr + 8 * j * rows * n2, 2 * rows)

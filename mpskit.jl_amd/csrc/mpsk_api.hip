@@ -2008,6 +2008,25 @@ static int tsplit_c128(mpsk_ctx* c, int m, int n, const void* theta, int ldt, in
   return MPSK_OK;
 }
 
+// conversions between an interleaved complex matrix (m x n complex = 2m x n doubles, ldh in DOUBLES) and its real embedding
+// (2m x 2n doubles): one launch each.  mpsk_cx_half returns the STRUCTURED PART of a nearly embedded matrix
+// (re = (E00 + E11) / 2, im = (E10 - E01) / 2 on every 2 x 2 block), which is the complex matrix whose embedding is closest.
+int mpsk_cx_embed(mpsk_ctx* c, int m, int n, const void* H, int64_t ldh, void* E, int64_t lde) {
+  REQUIRE(c && H && E, "NULL argument");
+  REQUIRE(m > 0 && n > 0 && ldh >= 2 * (int64_t)m && lde >= 2 * (int64_t)m, "bad dimensions");
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(cx_embed_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)H, ldh, m, n, (double*)E, lde);
+  return MPSK_OK;
+}
+int mpsk_cx_half(mpsk_ctx* c, int m, int n, const void* E, int64_t lde, void* H, int64_t ldh) {
+  REQUIRE(c && H && E, "NULL argument");
+  REQUIRE(m > 0 && n > 0 && ldh >= 2 * (int64_t)m && lde >= 2 * (int64_t)m, "bad dimensions");
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(cx_half_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)E, lde, m, n, (double*)H, ldh,
+                     (double*)nullptr, (int64_t)0, 0);
+  return MPSK_OK;
+}
+
 // the ABI entry: fp64, or complex128 when the ctx dtype says so (mpsk_ctx_set_dtype)
 int mpsk_tsplit(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
                 void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
