@@ -351,3 +351,137 @@ class CpuBackend:
 
     def prof_summary(self):
         return []
+
+
+class CpuComplexBackend(CpuBackend):
+    """CpuBackend + the MPSK_C128 entry points the interleaved complex host (mpskit_jl_amd.native_cplx) uses: interleaved
+    complex DTensors (shape (2 n0, n1, ...), Julia Array{ComplexF64} memory), complex MPO slices, prepared operator, complex
+    gauge steps / products / split -- all by NumPy complex arithmetic and the oracle.  Test infrastructure only."""
+
+    _cplx_mode = False
+
+    # ---- memory: interleaved complex
+    def upload_c(self, a):
+        a = np.asarray(a, dtype=np.complex128)
+        flat = np.ravel(a, order="F").view(np.float64).copy()
+        return DTensor(torch.from_numpy(flat), (2 * a.shape[0],) + tuple(a.shape[1:]))
+
+    def download_c(self, t):
+        flat = t.buf[: t.size].numpy().view(np.complex128)
+        return flat.reshape((t.shape[0] // 2,) + tuple(t.shape[1:]), order="F").copy()
+
+    def _set_c(self, t, arr):
+        t.buf[: t.size] = torch.from_numpy(np.ravel(np.asarray(arr, dtype=np.complex128), order="F").view(np.float64).copy())
+        return t
+
+    def upload_env_c(self, blocks):
+        slabs = [np.asarray(b, dtype=np.complex128)[:, k, :] for b in blocks for k in range(np.asarray(b).shape[1])]
+        flat = np.concatenate([np.ravel(s, order="F") for s in slabs]).view(np.float64).copy()
+        return DTensor(torch.from_numpy(flat), (len(slabs), 2 * slabs[0].shape[0], slabs[0].shape[1]))
+
+    def _env_c(self, t, chis):
+        W, Db2, Dk = t.shape
+        Db = Db2 // 2
+        flat = t.buf[: t.size].numpy().view(np.complex128)
+        slabs = [flat[w * Db * Dk:(w + 1) * Db * Dk].reshape((Db, Dk), order="F") for w in range(W)]
+        out, o = [], 0
+        for chi in chis:
+            out.append(np.stack(slabs[o:o + chi], axis=1))
+            o += chi
+        return out
+
+    def _put_env_c(self, blocks, out=None):
+        t = self.upload_env_c(blocks)
+        if out is not None:
+            out.buf[: t.size] = t.buf[: t.size]
+            return out
+        return t
+
+    def _set_dtype(self, cplx):
+        self._cplx_mode = bool(cplx)
+
+    def mposlice(self, odim, d, chil, chir, blocks, cplx=False):
+        s = HostSlice(odim, d, chil, chir, blocks)
+        s.cplx = bool(cplx)
+        return s
+
+    # ---- operators
+    class _Hac:
+        def __init__(self, be, H, GL, GR):
+            self.be, self.H, self.GL, self.GR = be, H, GL, GR
+
+        def apply(self, x, out=None, nblk=1):
+            be, H = self.be, self.H
+            be._count("hac_apply_c")
+            y = mo.dAC(be.download_c(x), H.oracle, be._env_c(self.GL, H.chil), be._env_c(self.GR, H.chir))
+            o = be.empty(self.GL.shape[1], x.shape[1], x.shape[2]) if out is None else out
+            return be._set_c(o, y)
+
+    def hac_create(self, H, GL, GR):
+        assert getattr(H, "cplx", False), "the stand-in only prepares complex operators"
+        return CpuComplexBackend._Hac(self, H, GL, GR)
+
+    def dC(self, GL, GR, c, out=None, cplx=False):
+        if not cplx:
+            return super().dC(GL, GR, c, out)
+        W = GL.shape[0]
+        y = mo.dC(self.download_c(c), self._env_c(GL, [1] * W), self._env_c(GR, [1] * W))
+        o = self.empty(GL.shape[1], c.shape[1]) if out is None else out
+        return self._set_c(o, y)
+
+    def dAC2(self, H1, H2, GL, GR, x2, out=None):
+        if not getattr(H1, "cplx", False):
+            return super().dAC2(H1, H2, GL, GR, x2, out)
+        y = mo.dAC2(self.download_c(x2), H1.oracle, H2.oracle, self._env_c(GL, H1.chil), self._env_c(GR, H2.chir))
+        o = self.empty(GL.shape[1], x2.shape[1], GR.shape[2], x2.shape[3]) if out is None else out
+        return self._set_c(o, y)
+
+    def transfer_left(self, H, GLin, A, Ab, out=None, cplx=False):
+        if not (cplx or getattr(H, "cplx", False)):
+            return super().transfer_left(H, GLin, A, Ab, out)
+        res = mo.transfer_left(self._env_c(GLin, H.chil), H.oracle, self.download_c(A), self.download_c(Ab))
+        return self._put_env_c(res, out)
+
+    def transfer_right(self, H, GRin, A, Ab, out=None, cplx=False):
+        if not (cplx or getattr(H, "cplx", False)):
+            return super().transfer_right(H, GRin, A, Ab, out)
+        res = mo.transfer_right(self._env_c(GRin, H.chir), H.oracle, self.download_c(A), self.download_c(Ab))
+        return self._put_env_c(res, out)
+
+    # ---- complex gauge steps / products / split (mpsk_qrpos, mpsk_lqpos, mpsk_gemm, mpsk_tsplit under MPSK_C128)
+    def qrpos_c(self, A):
+        self._count("qrpos_c")
+        q, r = mo.qrpos(self.download_c(A))
+        return self.upload_c(q), self.upload_c(r)
+
+    def lqpos_c(self, A):
+        self._count("lqpos_c")
+        l, q = mo.lqpos(self.download_c(A))
+        return self.upload_c(l), self.upload_c(q)
+
+    def gemm_c(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
+        a, b = self.download_c(A), self.download_c(B)
+        r = alpha * (a.conj().T if transA else a) @ (b.conj().T if transB else b)
+        if out is None:
+            return self.upload_c(r)
+        if beta != 0.0:
+            r = r + beta * self.download_c(out)
+        return self._set_c(out, r)
+
+    def gemm_raw(self, tA, tB, M, N, K, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc):
+        if not self._cplx_mode:
+            return super().gemm_raw(tA, tB, M, N, K, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc)
+        ar, ac = (K, M) if tA else (M, K)
+        br, bc = (N, K) if tB else (K, N)
+        cv = lambda p, ld, cols: _view(p, 2 * ld * cols).view(np.complex128).reshape((ld, cols), order="F")
+        a, b, c = cv(a_ptr, lda, ac)[:ar], cv(b_ptr, ldb, bc)[:br], cv(c_ptr, ldc, N)
+        r = alpha * (a.conj().T if tA else a) @ (b.conj().T if tB else b)
+        c[:M] = r + (beta * c[:M] if beta != 0.0 else 0.0)
+
+    def tsplit_c(self, theta, max_keep=0):
+        self._count("tsplit_c")
+        a = self.download_c(theta)
+        U, S, Vh = np.linalg.svd(a, full_matrices=False)
+        k = len(S) if not max_keep else min(len(S), int(max_keep))
+        return (self.upload_c(U[:, :k]), self.upload_c(np.diag(S[:k]).astype(complex)), self.upload_c(Vh[:k, :]), S[:k].copy(),
+                float(np.sqrt(np.sum(S[k:] ** 2))))

@@ -647,3 +647,62 @@ def test_fixed_budget_sweeps_on_a_converged_complex_state_stay_variational(cb):
         alg.dmrg_sweep(psi, H, envs, mk.Arnoldi(fixed_matvecs=6, krylovdim=6), ws)
         E = float(np.sum(mk.expectation_value(psi, H, envs)))
         assert E >= E0 - 1e-9 and abs(E - Ec) < 1e-8, (E, Ec, E0)
+
+
+def _vec(tensors):
+    v = tensors[0]
+    for t in tensors[1:]:
+        v = np.tensordot(v, t, axes=([-1], [0]))
+    return v.reshape(-1)
+
+
+def test_interleaved_complex_host_logic():
+    """mpskit_jl_amd.native_cplx on the complex CPU stand-in: the HOST logic of the interleaved-storage drivers (mixed-canonical
+    bookkeeping, environment extension, index permutations of the two-site tensors, the reference-named entry points) against
+    the oracle's complex128 DMRG / DMRG2 / TDVP / TDVP2; the GPU twins in tests/test_gpu_complex.py run the same drivers
+    through the C ABI."""
+    import mpskit_jl_amd as mk
+    from mpskit_jl_amd import native_cplx as nc
+    from cpu_backend import CpuComplexBackend
+    cb = CpuComplexBackend()
+    rng = np.random.default_rng(5)
+    L, d, D = 6, 2, 8
+    dims = mo.FiniteMPS.random(L, d, D, np.random.default_rng(0)).bond_dims()
+    As = [rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i])) + 1j * rng.standard_normal((1 if i == 0 else dims[i - 1], d, dims[i]))
+          for i in range(L)]
+    X = np.array([[0, 1], [1, 0]], dtype=complex); Y = np.array([[0, -1j], [1j, 0]]); Z = np.array([[1, 0], [0, -1]], dtype=complex)
+    H = nc.ComplexMPOHamiltonian({(0, 0): 1.0, (4, 4): 1.0, (0, 1): X, (1, 4): X, (0, 2): Y, (2, 4): Y, (0, 3): Z, (3, 4): Z}, cb)
+    Ho = mo.heisenberg_pauli_mpo()
+    eig = mk.Arnoldi(tol=1e-12, krylovdim=16, maxiter=40)
+    # one-site DMRG, sweep by sweep
+    psi = nc.NativeFiniteMPS(As, cb)
+    assert psi.bytes() == 16 * sum(int(np.prod(a.shape)) for a in As)
+    envs = nc.NativeFinEnv(psi, H)
+    po = mo.FiniteMPS(As, normalize=True)
+    for sweep in range(2):
+        E = nc.dmrg_sweep(psi, H, envs, eig)
+        po, _, _, log = mo.dmrg(po, Ho, maxiter=1, eig_tol=1e-12, krylovdim=16, eig_maxiter=40)
+        assert abs(E - log[-1][1]) < 1e-9 * abs(E)
+    # two-site DMRG growing the bond dimension from 2
+    dims2 = mo.FiniteMPS.random(L, d, 2, np.random.default_rng(0)).bond_dims()
+    Bs = [rng.standard_normal((1 if i == 0 else dims2[i - 1], d, dims2[i])) + 1j * rng.standard_normal((1 if i == 0 else dims2[i - 1], d, dims2[i]))
+          for i in range(L)]
+    psi = nc.NativeFiniteMPS(Bs, cb)
+    envs = nc.NativeFinEnv(psi, H)
+    po = mo.FiniteMPS(Bs, normalize=True)
+    for sweep in range(2):
+        E = nc.dmrg2_sweep(psi, H, envs, eig, trunc_dim=D)
+        po, _, _, log = mo.dmrg2(po, Ho, truncdim=D, maxiter=1, eig_tol=1e-12, krylovdim=16, eig_maxiter=40)
+        assert abs(E - log[-1][1]) < 1e-9 * abs(E)
+    assert abs(E - np.linalg.eigvalsh(mo.dense_hamiltonian(Ho, L))[0]) < 1e-8 * abs(E)
+    # real-time TDVP and TDVP2 steps
+    psi = nc.NativeFiniteMPS(As, cb)
+    psi, envs = nc.timestep(psi, H, 0.0, 0.05, mk.TDVP(tol=1e-12, krylovdim=16))
+    po2, _ = mo.tdvp_timestep(mo.FiniteMPS(As, normalize=True), Ho, 0.0, 0.05, tol=1e-12, krylovdim=16)
+    vo, vn = mo.mps_to_vector(po2), _vec(psi.to_host())
+    assert abs(abs(np.vdot(vo, vn)) - 1.0) < 1e-9 and abs(np.linalg.norm(vn) - 1.0) < 1e-10
+    psi = nc.NativeFiniteMPS(Bs, cb)
+    psi, envs = nc.timestep(psi, H, 0.0, 0.05, mk.TDVP2(tol=1e-12, krylovdim=16, trunc_dim=D))
+    po2, _ = mo.tdvp2_timestep(mo.FiniteMPS(Bs, normalize=True), Ho, 0.0, 0.05, truncdim=D, tol=1e-12, krylovdim=16)
+    vo, vn = mo.mps_to_vector(po2), _vec(psi.to_host())
+    assert abs(abs(np.vdot(vo, vn)) / (np.linalg.norm(vo) * np.linalg.norm(vn)) - 1.0) < 1e-9
