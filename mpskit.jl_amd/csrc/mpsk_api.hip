@@ -84,8 +84,8 @@ struct mpsk_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;          // transposed operands of mpsk_qrlq_pair
   size_t ws3_bytes = 0;
-  void* cxws[3] = {nullptr, nullptr, nullptr};     // scratch of the complex128 gauge steps (embedded operands; conjugate transposes; split)
-  size_t cxws_bytes[3] = {0, 0, 0};
+  void* cxws[4] = {nullptr, nullptr, nullptr, nullptr};   // scratch: complex gauge steps (embedded operands; conjugate transposes; split), rescaled theta
+  size_t cxws_bytes[4] = {0, 0, 0, 0};
   int* h_flags = nullptr;       // pinned [2]
   // deferred completion of a CholeskyQR gauge step (mpsk_ctx_qr_defer / mpsk_qr_commit): the launches are enqueued, the
   // success flag is read (and a fallback run) only at commit -- the caller fills the gap with work that does not need c->ws
@@ -183,7 +183,7 @@ int mpsk_ctx_destroy(mpsk_ctx* c) {
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->ws2) (void)hipFree(c->ws2);
   if (c->ws3) (void)hipFree(c->ws3);
-  for (int i = 0; i < 3; ++i) if (c->cxws[i]) (void)hipFree(c->cxws[i]);
+  for (int i = 0; i < 4; ++i) if (c->cxws[i]) (void)hipFree(c->cxws[i]);
   for (int i = 1; i < 3; ++i)
     if (c->xstreams[i]) { (void)hipStreamSynchronize(c->xstreams[i]); gemm_release_stream(c->xstreams[i]); (void)hipStreamDestroy(c->xstreams[i]); }
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -1574,6 +1574,29 @@ __global__ __launch_bounds__(256) void split_fill_nan_kernel(double* __restrict_
   if (e < n) y[e] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
+// X (rows x cols, ld) = alpha * A (lda)   /   leading rows x cols of the identity
+__global__ __launch_bounds__(256) void split_scale_copy_kernel(const double* __restrict__ A, int64_t lda, int rows, int cols,
+                                                               double alpha, double* __restrict__ X, int64_t ldx) {
+  const int64_t tot = (int64_t)rows * cols;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(t % rows), c = (int)(t / rows);
+    X[r + ldx * c] = A ? alpha * A[r + lda * c] : (r == c ? 1.0 : 0.0);
+  }
+}
+
+// *out = max |A[r, c]| as the bit pattern of a non-negative double (order preserving under unsigned compare); NaN -> +inf bits
+__global__ __launch_bounds__(256) void split_absmax_kernel(const double* __restrict__ A, int64_t lda, int rows, int cols,
+                                                           unsigned long long* __restrict__ out) {
+  const int64_t tot = (int64_t)rows * cols;
+  double mx = 0.0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+    const double v = fabs(A[(t % rows) + lda * (t / rows)]);
+    mx = (v > mx || v != v) ? (v != v ? INFINITY : v) : mx;
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
+}
+
 struct SplitSub {             // state of the subspace stage across refinements
   int r = 0;
   double *Yb = nullptr, *Zb = nullptr, *Wb = nullptr, *Bp = nullptr;   // nn x r, mm x r, nn x r, mm x r
@@ -1612,8 +1635,57 @@ static int split_iterate(mpsk_ctx* c, int mm, int nn, const double* Ap, int lda,
   return MPSK_OK;
 }
 
+static int tsplit_core(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
+                       void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm);
+
+// Front end of the fp64 split: every factorization inside squares the scale of theta (Gram matrices), so tensors whose norm
+// is outside [1e-100, 1e100] are split as theta / |theta|_F and the values scaled back (the split is homogeneous of degree
+// one: AL, AR unchanged, C, S, the discarded norm and trunc_err scale); theta = 0 gets the trivial answer (C = 0, any
+// isometries) instead of a factorization of nothing.
 static int tsplit_f64(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
                       void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
+  REQUIRE(c && theta && AL && Cm && AR && S && kept && disc_norm, "NULL argument");
+  REQUIRE(m > 0 && n > 0 && ldt >= m, "dimensions must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  // scale = max |theta_ij| (a norm would square the entries: 1e-200 underflows there already)
+  double nrm = 1.0;
+  {
+    unsigned long long* d_mx = (unsigned long long*)c->d_partial;
+    unsigned long long h_mx = 0;
+    HIPCHK(hipMemsetAsync(d_mx, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(split_absmax_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)theta, (int64_t)ldt, m, n, d_mx);
+    HIPCHK(hipMemcpyAsync(&h_mx, d_mx, sizeof(h_mx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::memcpy(&nrm, &h_mx, sizeof(double));
+  }
+  const int kfull = m < n ? m : n;
+  if (nrm == 0.0) {
+    const int k = (max_keep > 0 && max_keep < kfull) ? max_keep : kfull;
+    REQUIRE(ldal >= m && ldc >= k && ldar >= k, "leading dimension too small");
+    hipLaunchKernelGGL(split_scale_copy_kernel, dim3(256), dim3(256), 0, c->stream, (const double*)nullptr, (int64_t)0, m, k, 0.0, (double*)AL, (int64_t)ldal);
+    hipLaunchKernelGGL(split_scale_copy_kernel, dim3(256), dim3(256), 0, c->stream, (const double*)nullptr, (int64_t)0, k, n, 0.0, (double*)AR, (int64_t)ldar);
+    HIPCHK(hipMemset2DAsync(Cm, sizeof(double) * ldc, 0, sizeof(double) * k, k, c->stream));
+    HIPCHK(hipMemsetAsync(S, 0, sizeof(double) * kfull, c->stream));
+    *kept = k; *disc_norm = 0.0;
+    c->last_split_path = 0; c->last_split_iters = 0; c->last_split_resid = 0.0; c->last_svd_sweeps = 0;
+    return MPSK_OK;
+  }
+  if (std::isfinite(nrm) && (nrm < 1.0e-100 || nrm > 1.0e100)) {
+    double* Ts = nullptr;
+    if (int rc = cx_scratch(c, 3, sizeof(double) * (size_t)m * n, &Ts)) return rc;
+    hipLaunchKernelGGL(split_scale_copy_kernel, dim3(1024), dim3(256), 0, c->stream, (const double*)theta, (int64_t)ldt, m, n, 1.0 / nrm, Ts, (int64_t)m);
+    if (int rc = tsplit_core(c, m, n, Ts, m, max_keep, trunc_err / nrm, AL, ldal, Cm, ldc, AR, ldar, S, kept, disc_norm)) return rc;
+    const int k = *kept;
+    hipLaunchKernelGGL(split_scale_copy_kernel, dim3(256), dim3(256), 0, c->stream, (const double*)Cm, (int64_t)ldc, k, k, nrm, (double*)Cm, (int64_t)ldc);
+    HIPCHK(vec_scal(nrm, (double*)S, kfull, c->stream));
+    *disc_norm *= nrm;
+    return MPSK_OK;
+  }
+  return tsplit_core(c, m, n, theta, ldt, max_keep, trunc_err, AL, ldal, Cm, ldc, AR, ldar, S, kept, disc_norm);
+}
+
+static int tsplit_core(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
+                       void* AL, int ldal, void* Cm, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm) {
   REQUIRE(c && theta && AL && Cm && AR && S && kept && disc_norm, "NULL argument");
   REQUIRE(m > 0 && n > 0, "dimensions must be positive");
   const int mm = m < n ? n : m, nn = m < n ? m : n, transposed = m < n ? 1 : 0;
@@ -1814,6 +1886,13 @@ static int tsplit_f64(mpsk_ctx* c, int m, int n, const void* theta, int ldt, int
       if (getenv("MPSK_SVD_DEBUG"))
         fprintf(stderr, "[mpsk_tsplit] subspace stage: r = %d of %d, %d iterations, residual %.3e (tol %.1e), Ritz ratio s_r / s_k = %.3f, %d Jacobi sweeps\n",
                 r_sub, nn, q_total, rho, sub_tol, ratio, c->last_svd_sweeps);
+      // (the check is blind to a collapsed basis -- U_k = 0 has residual 0 -- so the kept left vectors must also be an isometry)
+      {
+        double un = 0.0;
+        if (!transposed) { if (int rc = mpsk_vnrm2(c, (int64_t)m * k, AL, &un)) return rc; }
+        else { if (int rc = mpsk_vnrm2(c, (int64_t)n * k, Vk, &un)) return rc; }
+        if (!(std::fabs(un * un - (double)k) <= 1.0e-8 * k) && !(ldal != m && !transposed)) rho = INFINITY;
+      }
       if (!(rho <= sub_tol)) {
         // not there: iterations still needed from the measured check value
         // (a Ritz ratio taken before convergence UNDERestimates sigma_{r+1} / sigma_k -- sigma~_r is still far below

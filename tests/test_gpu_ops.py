@@ -609,6 +609,34 @@ def test_tsplit_workspace_of_the_inner_factorizations_on_a_fresh_ctx(m, n, k, mo
         be2.close()
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_tsplit_extreme_scales_and_zero(be, mode):
+    """The factorizations inside the split square the scale of theta (Gram matrices): tensors of norm 1e-200 or 1e+150 used to
+    underflow / overflow there (zero 'isometries' accepted by the residual check, which a collapsed basis passes trivially).
+    The front end now splits theta / |theta| and scales C, S and the discarded norm back; theta = 0 gets C = 0 and isometries."""
+    rng = np.random.default_rng(3)
+    n, k = 512, 96
+    Uo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Vo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s0 = np.logspace(0, -6, n)
+    be.set_svd_mode(mode)
+    try:
+        for scale in (1e-200, 1e150, 1.0):
+            A = (Uo * (scale * s0)) @ Vo.T
+            al, c, ar, S, disc = be.tsplit(be.upload(A), max_keep=k)
+            a_, c_, r_ = be.download(al), be.download(c), be.download(ar)
+            assert np.abs(a_.T @ a_ - np.eye(k)).max() < 1e-12 and np.abs(r_ @ r_.T - np.eye(k)).max() < 1e-12
+            assert np.abs(S / scale - s0[:k]).max() < 1e-13
+            assert abs(disc / scale - np.linalg.norm(s0[k:])) < 1e-13
+            assert np.abs(a_ @ c_ @ r_ / scale - (Uo[:, :k] * s0[:k]) @ Vo[:, :k].T).max() < 1e-12
+        al, c, ar, S, disc = be.tsplit(be.upload(np.zeros((n, n))), max_keep=k)
+        a_, c_, r_ = be.download(al), be.download(c), be.download(ar)
+        assert np.abs(a_.T @ a_ - np.eye(k)).max() == 0.0 and np.abs(r_ @ r_.T - np.eye(k)).max() == 0.0
+        assert np.abs(c_).max() == 0.0 and np.abs(S).max() == 0.0 and disc == 0.0
+    finally:
+        be.set_svd_mode(3)
+
+
 def test_tsplit_dominance_probe_rejects_an_unconverged_subspace(be):
     """The last line of defence of svd mode 3: with the residual check disabled and a single subspace iteration (test hook
     MPSK_SPLIT_DEBUG_SKIP_CHECK), the kept subspace is far from the dominant one, the remainder theta - AL M contains
