@@ -247,7 +247,9 @@ int mpsk_tsvd(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, void* U, 
  * AL C AR = theta projected on the kept singular subspace, C is TRIANGULAR instead of diag(S) -- lower or upper depending on
  * the orientation and on the svd mode (mode 2 delivers the left vectors of the tall orientation, the other factor comes from
  * an LQpos); S (min(m, n) doubles) receives all singular values (svd mode 3: see mpsk_ctx_set_svd_mode), *kept = k.
- * Buffers: AL m x min(m,n), C min(m,n)^2, AR min(m,n) x n (only the leading k columns / rows are written). */
+ * Buffers: AL m x min(m,n), C min(m,n)^2, AR min(m,n) x n (only the leading k columns / rows are written).
+ * Any scale: a theta whose largest entry is outside [1e-100, 1e100] is split as theta / max|theta_ij| (C, S, disc_norm scaled
+ * back); theta = 0 returns C = 0 with identity isometries. */
 int mpsk_tsplit(mpsk_ctx* ctx, int m, int n, const void* theta, int ldt, int max_keep, double trunc_err,
                 void* AL, int ldal, void* C, int ldc, void* AR, int ldar, void* S, int* kept, double* disc_norm);
 /* Interleaved complex matrix (m x n complex: 2m x n doubles, ldh in doubles) <-> its real 2m x 2n embedding
